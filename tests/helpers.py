@@ -1,0 +1,127 @@
+"""Shared builders for small vocabularies and adversarial texts (own code, seeded)."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from hutoken_amd import vocab_files as vf  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+HU = "áéíóöőúüűÁÉÍÓÖŐÚÜŰ"
+CJK = "漢字仮名交じり文中文測試"
+EMOJI = "😂🙂🚀"
+ODD = " €—…«»"
+
+
+def random_byte_vocab(seed, n_merges=300, proper=True, dup_ids=False, neg_ids=False):
+    """GPT-2-shaped byte-level vocabulary: 256 byte tokens then `n_merges`
+    tokens that are concatenations of two earlier tokens (proper=True) or
+    arbitrary short byte strings with shuffled ids (proper=False).
+    Returns (entries [(visible-bytes, id)], special mapping)."""
+    rng = random.Random(seed)
+    t = vf.bytes_to_unicode()
+    order = vf.byte_token_order()
+    raw_tokens = [bytes([b]) for b in order]
+    alphabet = (b"etaoinshrdlucmfwypvbgkqjxz" * 3 + b" " * 6 + b"ETAOIN0123456789.,!?\n\t"
+                + "áéőű漢😂".encode("utf-8"))
+    seen = set(raw_tokens)
+    while len(raw_tokens) < 256 + n_merges:
+        if proper:
+            a = rng.choice(raw_tokens[: max(256, len(raw_tokens))])
+            b = rng.choice(raw_tokens)
+            if rng.random() < 0.7:
+                a = bytes([rng.choice(alphabet)]) if rng.random() < 0.5 else a
+            tok = a + b
+        else:
+            tok = bytes(rng.choice(alphabet) for _ in range(rng.randint(2, 5)))
+        if tok in seen or len(tok) > 12:
+            continue
+        seen.add(tok)
+        raw_tokens.append(tok)
+    ids = list(range(len(raw_tokens)))
+    if not proper:
+        tail = ids[256:]
+        rng.shuffle(tail)
+        ids[256:] = tail
+    if dup_ids:
+        for _ in range(n_merges // 10):
+            i = rng.randrange(256, len(ids))
+            ids[i] = ids[rng.randrange(256, len(ids))]
+    if neg_ids:
+        for _ in range(n_merges // 20):
+            ids[rng.randrange(256, len(ids))] = rng.choice([-1, -2, -7])
+    entries = [(vf.encode_visible(tok, t), i) for tok, i in zip(raw_tokens, ids)]
+    return entries, vf.gpt2_special_mapping()
+
+
+def random_char_vocab(seed, n_merges=300, drop_chars=""):
+    """SentencePiece/Llama-shaped vocabulary (is_byte_encoder=False,
+    prefix U+2581): single characters, byte-fallback literals <0xHH>, and
+    merges of earlier tokens.  Characters in `drop_chars` are left out so that
+    they encode to -1 yet can still appear inside longer tokens."""
+    rng = random.Random(seed)
+    chars = list("▁etaoinshrdlucmfwypvbgkqjxzETAOIN0123456789.,!?-") + list(HU) + list(CJK[:6])
+    toks = ["<0x%02X>" % b for b in range(256)]
+    toks += [c for c in chars if c not in drop_chars]
+    base = list(chars)
+    seen = set(toks)
+    while len(toks) < 256 + len(chars) + n_merges:
+        a = rng.choice(base if rng.random() < 0.5 else toks[256:])
+        b = rng.choice(base if rng.random() < 0.5 else toks[256:])
+        tok = a + b
+        if tok in seen or len(tok) > 10:
+            continue
+        seen.add(tok)
+        toks.append(tok)
+    entries = [(tk.encode("utf-8"), i) for i, tk in enumerate(toks)]
+    return entries, vf.llama_special_mapping()
+
+
+def write_vocab(tmpdir, name, entries, special):
+    vp = os.path.join(str(tmpdir), name + "_vocab.txt")
+    sp = os.path.join(str(tmpdir), name + "_special.txt")
+    vf.write_vocab_file(vp, entries)
+    vf.write_special_file(sp, special)
+    return vp, sp
+
+
+def random_text(rng, max_words=12, exotic=0.3):
+    """Valid-UTF-8 text that exercises every splitter rule."""
+    parts = []
+    for _ in range(rng.randint(0, max_words)):
+        r = rng.random()
+        if r < 0.45:
+            w = "".join(rng.choice("etaoinshrdlucmfwypvbgkqjxz") for _ in range(rng.randint(1, 9)))
+            if rng.random() < 0.15:
+                w = w.capitalize()
+        elif r < 0.55:
+            w = "".join(rng.choice("0123456789") for _ in range(rng.randint(1, 5)))
+        elif r < 0.65:
+            w = "".join(rng.choice(".,!?-()\"'") for _ in range(rng.randint(1, 3)))
+        elif r < 0.65 + exotic * 0.4:
+            w = "".join(rng.choice("aeiou" + HU) for _ in range(rng.randint(1, 7)))
+        elif r < 0.65 + exotic * 0.7:
+            w = "".join(rng.choice(CJK) for _ in range(rng.randint(1, 5)))
+        elif r < 0.65 + exotic * 0.85:
+            w = rng.choice(EMOJI) * rng.randint(1, 2)
+        else:
+            w = rng.choice(ODD)
+        sep = rng.choice([" "] * 12 + ["  ", "   ", "\n", "\t", "\r\n", "", "", ", ", ". "])
+        parts.append(w + sep)
+    s = "".join(parts)
+    if rng.random() < 0.2:
+        s = " " + s
+    return s
+
+
+def random_bytes_text(rng, n):
+    """Arbitrary bytes without 0x00: truncated and invalid UTF-8 included."""
+    pool = [b"a", b"b", b" ", b"  ", b"1", b".", b"\t", b"\xc3\xa9", b"\xc5\x91", b"\xe6\xbc\xa2",
+            b"\xf0\x9f\x98\x82", b"\xc3", b"\xe6\xbc", b"\xf0\x9f", b"\x80", b"\xbf", b"\xff",
+            b"\xc0\xa0", b"\xc1\xa1", b"\xc0\x80", b"\xc2\xa0", b"\xc2\x85", b"\xe0\x80\x80", b"\n"]
+    out = b"".join(rng.choice(pool) for _ in range(n))
+    return out
