@@ -1,0 +1,199 @@
+"""hutoken_amd -- MI355X-native batch BPE encode path behind huToken's Python surface.
+
+`import hutoken_amd as hutoken` is the drop-in for the encode direction of the
+reference's `hutoken` module (reference hutoken.py:22-43, 122-139):
+
+    hutoken.initialize(vocab_file, special_chars_file, prefix=None, is_byte_encoder=False)
+    hutoken.encode(text)                      -> list[int]
+    hutoken.batch_encode(texts, num_threads)  -> list[list[int]]
+
+Signatures, return types, exception classes and the messages the reference's tests
+pin are kept.  Token ids are bit-exact with the reference's string-keyed path.
+The work is done by hand-written HIP kernels behind the C ABI of
+include/hutoken_amd.h; there is no CPU fallback: without the native library or a
+GPU every call raises.
+
+Also here (not in the reference): `encode_packed` / `encode_packed_device`, the
+zero-marshalling entry points for packed UTF-8 + offsets.
+"""
+import os
+import sys
+import traceback
+
+from . import _capi
+
+__all__ = ["initialize", "encode", "batch_encode", "encode_packed", "encode_packed_device",
+           "decode", "batch_decode", "context"]
+
+_NOT_INIT = ("Vocabulary is not initialized for encoding. "
+             "Call 'initialize_encode' function first.")
+_BAD_INIT_ARGS = ("Invalid arguments. Expected a string "
+                  "(vocab_file_path), a string (special_file_path), "
+                  "a string or None (prefix) a bool an"
+                  "optional integer (special_token_id), "
+                  " an optional string (regex_pattern) and"
+                  "a string or None (merges_file_path)")
+_WORD_TOO_LARGE = "A single word in the input text is too large to be processed."
+
+# process-global context, like the reference's global_encode_context (lib.c:73-74)
+_ctx = None
+
+
+def context():
+    """The current hutoken_amd._capi.Context (None before initialize())."""
+    return _ctx
+
+
+def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_encoder=False,
+                       special_token_id=-1, pattern=None, merges_file_path=None, device=-1):
+    # mirrors the argument contract of _hutoken.initialize (lib.c:188-215, "ss|zpizz")
+    global _ctx
+    if not isinstance(vocab_file_path, str) or not isinstance(special_file_path, str) \
+            or not (prefix is None or isinstance(prefix, str)) \
+            or not (pattern is None or isinstance(pattern, str)) \
+            or not (merges_file_path is None or isinstance(merges_file_path, str)) \
+            or not isinstance(special_token_id, int):
+        raise TypeError(_BAD_INIT_ARGS)
+    if pattern is not None:
+        raise RuntimeError("hutoken_amd: the regex `pattern` pre-token path (core.c:350-360) is outside "
+                           "the MI355X encode path; initialise with pattern=None")
+    if merges_file_path is not None:
+        raise RuntimeError("hutoken_amd: the id-keyed merge path (merges file, core.c:211-337) is outside "
+                           "the MI355X encode path; initialise without a merges file")
+    new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device)
+    old, _ctx = _ctx, new
+    if old is not None:
+        old.close()
+    return None
+
+
+def initialize(model_or_path, *args, **kwargs):
+    """hutoken.initialize (reference hutoken.py:22-120).  Local vocabulary files
+    only: the Hugging Face branch needs the network and `transformers` to fetch a
+    tokenizer and is not part of this path."""
+    if os.path.isfile(model_or_path):
+        special_chars_file = args[0] if args else None
+        merges_file = args[6] if len(args) > 6 else None
+        if special_chars_file and not os.path.isfile(special_chars_file):
+            raise ValueError(f"Special characters file '{special_chars_file}' does not exist.")
+        if merges_file and not os.path.isfile(merges_file):
+            raise ValueError(f"The provided merges file '{merges_file}' does not exist.")
+        prefix = kwargs.get("prefix", None)
+        is_byte_encoder = kwargs.get("is_byte_encoder", False)
+        token_id = kwargs.get("token_id", -1)
+        regex_pattern = kwargs.get("pattern", None)
+        device = kwargs.get("device", int(os.environ.get("HUTOKEN_DEVICE", "-1")))
+        return _native_initialize(model_or_path, special_chars_file, prefix, is_byte_encoder, token_id,
+                                  regex_pattern, device=device)
+    raise ValueError("Could not download Hugging Face tokenizer "
+                     f"'{model_or_path}': hutoken_amd loads local vocabulary files only")
+
+
+def _pack(texts):
+    import numpy as np
+    chunks = []
+    offs = np.zeros(len(texts) + 1, dtype=np.int64)
+    for i, t in enumerate(texts):
+        if not isinstance(t, str):
+            raise TypeError("bad argument type for built-in operation")
+        b = t.encode("utf-8")  # a lone surrogate raises UnicodeEncodeError (reference: crash)
+        z = b.find(b"\0")
+        if z >= 0:
+            b = b[:z]  # strdup() semantics of lib.c:770-772
+        chunks.append(b)
+        offs[i + 1] = offs[i] + len(b)
+    return np.frombuffer(b"".join(chunks), dtype=np.uint8), offs
+
+
+def _native_encode(text):
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT)
+    if not isinstance(text, str):
+        raise TypeError(f"argument 1 must be str, not {type(text).__name__}")
+    data = text.encode("utf-8")
+    if b"\0" in data:
+        raise ValueError("embedded null character")
+    ids, _rc = _ctx.encode_one(data)  # an over-long word is not reported (lib.c:692-697)
+    return ids
+
+
+def _native_batch_encode(texts, num_threads=1):
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT)
+    if not isinstance(texts, list):
+        raise TypeError("Invalid arguments. Expected a list of strings.")
+    if not isinstance(num_threads, int):
+        raise TypeError("Invalid arguments. Expected a list of strings.")
+    data, offs = _pack(texts)
+    if num_threads <= 0:
+        return [[] for _ in texts]  # no worker starts (lib.c:784-791)
+    ids, oo, _st, rc = _ctx.encode_packed(data, offs)
+    if rc == _capi.E_WORD_TOO_LARGE:
+        raise RuntimeError(_WORD_TOO_LARGE)  # lib.c:796-808
+    flat = ids.tolist()
+    bounds = oo.tolist()
+    return [flat[bounds[i]:bounds[i + 1]] for i in range(len(texts))]
+
+
+def encode(text):
+    try:
+        return _native_encode(text)
+    except Exception as e:
+        traceback.print_exc(file=sys.stderr)
+        raise RuntimeError(f"hutoken: Error encoding text: {e}")
+
+
+def batch_encode(texts, num_threads=1):
+    try:
+        return _native_batch_encode(texts, num_threads)
+    except Exception as e:
+        traceback.print_exc(file=sys.stderr)
+        raise RuntimeError(f"hutoken: Error encoding texts: {e}")
+
+
+def encode_packed(data, offsets):
+    """Packed UTF-8 (uint8 array) + int64 offsets[n+1] on the host ->
+    (ids int32 array, out_offsets int64[n+1], status int32[n]).  Raises like
+    batch_encode."""
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT)
+    ids, oo, st, rc = _ctx.encode_packed(data, offsets)
+    if rc == _capi.E_WORD_TOO_LARGE:
+        raise RuntimeError(_WORD_TOO_LARGE)
+    return ids, oo, st
+
+
+def encode_packed_device(d_bytes, d_offsets, check=True):
+    """Device-resident torch tensors in (uint8 bytes, int64 offsets[n+1]), device
+    tensors out: (ids int32[capacity], out_offsets int64[n+1]).  The ids of
+    document i are ids[out_offsets[i]:out_offsets[i+1]].  Asynchronous on the
+    current torch stream unless check=True, which synchronises and raises on a
+    device-side error."""
+    import torch
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT)
+    n_docs = d_offsets.numel() - 1
+    n_bytes = d_bytes.numel()
+    cap = _ctx.ids_capacity(n_bytes, n_docs)
+    dev = d_bytes.device
+    ids = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    oo = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _ctx.encode_device(d_bytes.data_ptr(), d_offsets.data_ptr(), n_docs, n_bytes, ids.data_ptr(), cap,
+                       oo.data_ptr(), 0, err.data_ptr(), stream)
+    if check:
+        code = int(err.item())
+        if code == _capi.E_WORD_TOO_LARGE:
+            raise RuntimeError(_WORD_TOO_LARGE)
+        if code != 0:
+            raise RuntimeError(f"hutoken_amd: device-side error {code}")
+    return ids, oo
+
+
+def decode(tokens):
+    raise RuntimeError("hutoken: Error decoding tokens: hutoken_amd provides the encode direction only")
+
+
+def batch_decode(tokens, num_threads=1):
+    raise RuntimeError("hutoken: Error decoding tokens: hutoken_amd provides the encode direction only")

@@ -1,0 +1,170 @@
+"""ctypes binding of include/hutoken_amd.h (the C-ABI shared library).
+
+The library is built in-tree (hutoken_amd/lib/libhutoken_amd.so).  Nothing here
+computes token ids: if the library or a GPU is missing the calls raise.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK = 0
+E_FILE_NOT_FOUND, E_VALUE, E_MEMORY, E_ARG, E_DEVICE, E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+E_CAPACITY, E_NUL_BYTE, E_WORD_TOO_LARGE, E_INVALID_UTF8 = 7, 8, 9, 10
+DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
+
+# every symbol include/hutoken_amd.h declares
+EXPORTS = [
+    "hutk_ctx_create", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
+    "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size",
+    "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
+    "hutk_set_timing",
+]
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_HIP
+
+
+def load(build_if_missing=True):
+    """Load libhutoken_amd.so (building it with hipcc when it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_HIP
+    if build_if_missing and (not os.path.exists(path) or os.environ.get("HUTOKEN_AMD_REBUILD")):
+        _build.build_hip()
+    if not os.path.exists(path):
+        raise RuntimeError("hutoken_amd: native library %s is missing (run `python -m hutoken_amd.build`)" % path)
+    L = C.CDLL(path)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.hutk_ctx_create.restype = i32
+    L.hutk_ctx_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, i32]
+    L.hutk_ctx_destroy.restype = None
+    L.hutk_ctx_destroy.argtypes = [vp]
+    L.hutk_last_error.restype = C.c_char_p
+    L.hutk_last_error.argtypes = []
+    L.hutk_ids_capacity.restype = i64
+    L.hutk_ids_capacity.argtypes = [vp, i64, i64]
+    L.hutk_encode_batch.restype = i32
+    L.hutk_encode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp]
+    L.hutk_encode_batch_device.restype = i32
+    L.hutk_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]
+    L.hutk_encode.restype = i32
+    L.hutk_encode.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(C.c_int32)]
+    L.hutk_vocab_size.restype = i64
+    L.hutk_vocab_size.argtypes = [vp]
+    L.hutk_pair_table_entries.restype = i64
+    L.hutk_pair_table_entries.argtypes = [vp]
+    L.hutk_device_ordinal.restype = i32
+    L.hutk_device_ordinal.argtypes = [vp]
+    L.hutk_last_timing.restype = i32
+    L.hutk_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hutk_set_timing.restype = None
+    L.hutk_set_timing.argtypes = [vp, i32]
+    L.hutk_table_stats.restype = i32
+    L.hutk_table_stats.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().hutk_last_error().decode("utf-8", "replace")
+
+
+_EXC = {E_FILE_NOT_FOUND: FileNotFoundError, E_VALUE: ValueError, E_MEMORY: MemoryError,
+        E_ARG: TypeError, E_DEVICE: RuntimeError, E_UNSUPPORTED: ValueError,
+        E_CAPACITY: RuntimeError, E_NUL_BYTE: ValueError, E_WORD_TOO_LARGE: RuntimeError,
+        E_INVALID_UTF8: ValueError}
+
+
+def raise_for(code):
+    if code != OK:
+        raise _EXC.get(code, RuntimeError)(last_error())
+
+
+class Context:
+    """Owns one hutk_ctx."""
+
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, device=-1):
+        L = load()
+        h = C.c_void_p()
+        rc = L.hutk_ctx_create(C.byref(h), os.fsencode(vocab_path), os.fsencode(special_path),
+                               None if prefix is None else prefix.encode("utf-8"),
+                               1 if is_byte_encoder else 0, device)
+        raise_for(rc)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().hutk_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def ids_capacity(self, n_bytes, n_docs):
+        return load().hutk_ids_capacity(self._h, n_bytes, n_docs)
+
+    def table_stats(self):
+        import numpy as np
+        out = np.zeros(8, dtype=np.int64)
+        raise_for(load().hutk_table_stats(self._h, out.ctypes.data))
+        keys = ["n_keys", "n_vocab_sym", "n_sym", "n_pairs", "pair_slots", "rank_is_sym", "ident_ids", "n_prefix"]
+        return dict(zip(keys, out.tolist()))
+
+    def encode_packed(self, data, offsets, want_status=True):
+        """Host numpy buffers in, host numpy buffers out.
+        -> (ids int32, out_offsets int64, status int32, return code)"""
+        import numpy as np
+        L = load()
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        nbytes = int(offsets[n]) if n >= 0 else 0
+        cap = self.ids_capacity(nbytes, n)
+        ids = np.empty(max(cap, 1), dtype=np.int32)
+        oo = np.zeros(n + 1, dtype=np.int64)
+        st = np.zeros(max(n, 1), dtype=np.int32)
+        rc = L.hutk_encode_batch(self._h, data.ctypes.data if nbytes else None, offsets.ctypes.data, n,
+                                 ids.ctypes.data, cap, oo.ctypes.data, st.ctypes.data)
+        if rc not in (OK, E_WORD_TOO_LARGE):
+            raise_for(rc)
+        return ids[: int(oo[n])], oo, st[:n], rc
+
+    def encode_one(self, data: bytes):
+        """-> (ids list, return code)"""
+        import numpy as np
+        L = load()
+        n = len(data)
+        cap = self.ids_capacity(n, 1)
+        ids = np.empty(max(cap, 1), dtype=np.int32)
+        n_ids = C.c_int64(0)
+        st = C.c_int32(0)
+        buf = C.create_string_buffer(data, n) if n else None
+        rc = L.hutk_encode(self._h, C.cast(buf, C.c_void_p) if n else None, n, ids.ctypes.data, cap,
+                           C.byref(n_ids), C.byref(st))
+        if rc not in (OK, E_WORD_TOO_LARGE):
+            raise_for(rc)
+        return ids[: n_ids.value].tolist(), rc
+
+    def encode_device(self, d_bytes, d_offsets, n_docs, n_bytes, d_ids, ids_cap, d_out_offsets,
+                      d_status=0, d_err=0, stream=0):
+        """Raw device pointers (ints); asynchronous on `stream`."""
+        rc = load().hutk_encode_batch_device(self._h, d_bytes, d_offsets, n_docs, n_bytes, d_ids, ids_cap,
+                                             d_out_offsets, d_status or None, d_err or None, stream or None)
+        raise_for(rc)
+
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        raise_for(load().hutk_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,456 @@
+// hutk_api.cpp -- C ABI of include/hutoken_amd.h: context life cycle, device
+// tables, workspace and the launch sequence of one batch.
+//
+// There is no CPU compute path in this file: every encode entry point enqueues the
+// HIP kernels of hutk_kernels.hip or fails with HUTK_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "hutk_device.h"
+
+using namespace hutk;
+
+namespace {
+thread_local std::string g_err = "";
+
+int set_err(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return set_err(HUTK_E_DEVICE, std::string("HIP error: ") + hipGetErrorString(e__) + \
+                                              " at " #expr);                                    \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+}  // namespace
+
+struct hutk_ctx {
+    Tables tab;
+    int device = -1;
+    bool host_only = false;
+    bool timing = true;
+
+    // device tables
+    DevBuf<uint64_t> d_pair, d_char;
+    DevBuf<int32_t> d_sym_id, d_prefix_alone;
+    DevBuf<uint32_t> d_item_sym, d_prefix_syms;
+    DevBuf<uint8_t> d_item_direct;
+    DevTables dt{};
+
+    // workspace
+    DevBuf<int32_t> w_run, w_exc_tok;
+    DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
+    DevBuf<int64_t> w_tile_i64;
+    DevBuf<ExcRec> w_exc;
+    DevBuf<int32_t> w_err;
+
+    // staging for the host-buffer entry point
+    DevBuf<uint8_t> s_bytes;
+    DevBuf<int64_t> s_offsets, s_out_offsets;
+    DevBuf<int32_t> s_ids, s_status;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+namespace {
+
+int upload_tables(hutk_ctx* c) {
+    Tables& T = c->tab;
+#define UP(buf, vec)                                                                            \
+    do {                                                                                        \
+        HIP_TRY((buf).reserve((vec).size() ? (vec).size() : 1));                                \
+        if ((vec).size())                                                                       \
+            HIP_TRY(hipMemcpy((buf).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice)); \
+    } while (0)
+    UP(c->d_pair, T.pair_slots);
+    UP(c->d_char, T.char_slots);
+    UP(c->d_sym_id, T.sym_id);
+    UP(c->d_prefix_syms, T.prefix_syms);
+#undef UP
+    HIP_TRY(c->d_item_sym.reserve(256));
+    HIP_TRY(hipMemcpy(c->d_item_sym.p, T.item_sym, sizeof T.item_sym, hipMemcpyHostToDevice));
+    HIP_TRY(c->d_item_direct.reserve(256));
+    HIP_TRY(hipMemcpy(c->d_item_direct.p, T.item_direct, sizeof T.item_direct, hipMemcpyHostToDevice));
+    HIP_TRY(c->d_prefix_alone.reserve(EXC_LDS_UNITS));
+
+    DevTables& D = c->dt;
+    D.pair_slots = c->d_pair.p;
+    D.pair_mask = T.pair_mask;
+    D.pair_shift = T.pair_shift;
+    D.sym_id = c->d_sym_id.p;
+    D.n_vocab_sym = T.n_vocab_sym;
+    D.n_sym = T.n_sym;
+    D.item_sym = c->d_item_sym.p;
+    D.item_direct = c->d_item_direct.p;
+    D.char_slots = c->d_char.p;
+    D.char_mask = T.char_mask;
+    D.char_shift = T.char_shift;
+    D.prefix_syms = c->d_prefix_syms.p;
+    D.n_prefix = (int32_t)T.prefix_syms.size();
+    D.prefix_alone_ids = c->d_prefix_alone.p;
+    D.n_prefix_alone = 0;
+    D.is_byte_encoder = T.is_byte_encoder;
+    D.has_prefix = T.has_prefix;
+    D.rank_is_sym = T.rank_is_sym;
+    D.ident_ids = T.ident_ids;
+
+    // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
+    // context: merge its units once, on the device, with the batch path's own loop
+    if (T.has_prefix && !T.prefix_alone_syms.empty()) {
+        if (T.prefix_alone_syms.size() > (size_t)EXC_LDS_UNITS)
+            return set_err(HUTK_E_UNSUPPORTED, "prefix too long");
+        DevBuf<uint32_t> d_syms;
+        DevBuf<int32_t> d_n;
+        HIP_TRY(d_syms.reserve(T.prefix_alone_syms.size()));
+        HIP_TRY(d_n.reserve(1));
+        HIP_TRY(hipMemcpy(d_syms.p, T.prefix_alone_syms.data(), T.prefix_alone_syms.size() * 4,
+                          hipMemcpyHostToDevice));
+        launch_bpe_symbols(D, d_syms.p, (int)T.prefix_alone_syms.size(), c->d_prefix_alone.p, d_n.p, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        int32_t n = 0;
+        HIP_TRY(hipMemcpy(&n, d_n.p, 4, hipMemcpyDeviceToHost));
+        D.n_prefix_alone = n;
+        d_syms.release();
+        d_n.release();
+    }
+    return HUTK_OK;
+}
+
+int pad_per_doc(const hutk_ctx* c) {
+    return c->tab.has_prefix ? (int)(c->tab.prefix_syms.size() + c->tab.prefix_alone_syms.size()) : 0;
+}
+
+// tile metadata packs five uint32 arrays and two int64 arrays into two allocations
+int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_tiles, Workspace& W) {
+    const int64_t pad = pad_per_doc(c);
+    const size_t run_elems = (size_t)(n_tiles * TILE_BYTES + 512);
+    const size_t exc_elems = (size_t)(n_bytes + pad * (n_docs + 2) + 512);
+    HIP_TRY(c->w_run.reserve(run_elems));
+    HIP_TRY(c->w_exc_tok.reserve(exc_elems));
+    HIP_TRY(c->w_exc_sym.reserve(exc_elems));
+    HIP_TRY(c->w_exc_mrg.reserve(exc_elems));
+    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 5 + 8));
+    HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + 8));
+    HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
+    HIP_TRY(c->w_counters.reserve(4));
+    HIP_TRY(c->w_err.reserve(1));
+    const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
+    HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
+    W.run = c->w_run.p;
+    W.exc_tok = c->w_exc_tok.p;
+    W.exc_sym = c->w_exc_sym.p;
+    W.exc_mrg = c->w_exc_mrg.p;
+    uint32_t* u = c->w_tile_u32.p;
+    W.tile_count = u;
+    W.tile_dense = u + n_tiles;
+    W.tile_run_start = u + 2 * n_tiles;
+    W.tile_exc_first = u + 3 * n_tiles;
+    W.tile_nexc = u + 4 * n_tiles;
+    W.tile_first_doc = c->w_tile_i64.p;
+    W.tile_base = c->w_tile_i64.p + n_tiles;
+    W.doc_tile_pos = c->w_doc_pos.p;
+    W.exc = c->w_exc.p;
+    W.counters = c->w_counters.p;
+    W.cap_exc = cap_exc;
+    W.pad_per_doc = (int32_t)pad;
+    return HUTK_OK;
+}
+
+void destroy(hutk_ctx* c) {
+    if (!c) return;
+    if (!c->host_only && c->device >= 0) {
+        (void)hipSetDevice(c->device);
+        c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_item_direct.release();
+        c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
+        c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
+        c->w_exc.release(); c->w_err.release();
+        c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
+        c->s_status.release();
+        for (auto& e : c->ev)
+            if (e) (void)hipEventDestroy(e);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hutk_last_error(void) { return g_err.c_str(); }
+
+int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_path,
+                    const char* prefix, int is_byte_encoder, int device) {
+    if (!out) return set_err(HUTK_E_ARG, "out is NULL");
+    *out = nullptr;
+    if (!vocab_path || !special_path)
+        return set_err(HUTK_E_ARG,
+                       "Invalid arguments. Expected a string (vocab_file_path), a string "
+                       "(special_file_path)");
+    hutk_ctx* c = new (std::nothrow) hutk_ctx();
+    if (!c) return set_err(HUTK_E_MEMORY, "out of memory");
+    LoadError le = load_tables(vocab_path, special_path, prefix, is_byte_encoder != 0, c->tab);
+    if (le.code) {
+        delete c;
+        return set_err(le.code, le.msg);
+    }
+    if (device == -2) {  // host-only context: tables for inspection, no encode
+        c->host_only = true;
+        *out = c;
+        return HUTK_OK;
+    }
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        delete c;
+        return set_err(HUTK_E_DEVICE,
+                       "no HIP device available: the hutoken_amd encode path runs on the GPU only");
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n_dev) {
+        delete c;
+        return set_err(HUTK_E_ARG, "device ordinal out of range");
+    }
+    c->device = device;
+    int rc = HUTK_OK;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { rc = set_err(HUTK_E_DEVICE, "hipSetDevice failed"); break; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = set_err(HUTK_E_DEVICE, "hipStreamCreate failed");
+            break;
+        }
+        bool ok = true;
+        for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+        if (!ok) { rc = set_err(HUTK_E_DEVICE, "hipEventCreate failed"); break; }
+        rc = upload_tables(c);
+    } while (0);
+    if (rc) {
+        std::string keep = g_err;
+        destroy(c);
+        g_err = keep;
+        return rc;
+    }
+    *out = c;
+    return HUTK_OK;
+}
+
+void hutk_ctx_destroy(hutk_ctx* ctx) { destroy(ctx); }
+
+int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs) {
+    if (!ctx) return 0;
+    return n_bytes + (int64_t)pad_per_doc(ctx) * n_docs + 1;
+}
+
+int64_t hutk_vocab_size(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_keys : 0; }
+int64_t hutk_pair_table_entries(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs : 0; }
+int hutk_device_ordinal(const hutk_ctx* ctx) { return ctx ? ctx->device : -1; }
+void hutk_set_timing(hutk_ctx* ctx, int enabled) {
+    if (ctx) ctx->timing = enabled != 0;
+}
+
+int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8) {
+    if (!ctx || !out8) return HUTK_E_ARG;
+    const Tables& T = ctx->tab;
+    out8[0] = T.n_keys;
+    out8[1] = T.n_vocab_sym;
+    out8[2] = T.n_sym;
+    out8[3] = T.n_pairs;
+    out8[4] = (int64_t)T.pair_slots.size();
+    out8[5] = T.rank_is_sym;
+    out8[6] = T.ident_ids;
+    out8[7] = (int64_t)T.prefix_syms.size();
+    return HUTK_OK;
+}
+
+int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets,
+                             int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap,
+                             int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err,
+                             void* hip_stream) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
+    if (n_docs < 0 || n_bytes < 0 || !d_offsets || !d_out_offsets || (n_bytes > 0 && (!d_bytes || !d_ids_out)))
+        return set_err(HUTK_E_ARG, "bad argument");
+    if (((uintptr_t)d_bytes & 15u) != 0) return set_err(HUTK_E_ARG, "d_bytes must be 16-byte aligned");
+    if (ids_cap < hutk_ids_capacity(c, n_bytes, n_docs) - 1)
+        return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const int64_t n_tiles = (n_bytes + TILE_BYTES - 1) / TILE_BYTES;
+    if (n_tiles > 0x7FFFFFFFll) return set_err(HUTK_E_ARG, "batch too large");
+    Workspace W{};
+    int rc = ensure_workspace(c, n_bytes, n_docs, n_tiles, W);
+    if (rc) return rc;
+    BatchArgs A{};
+    A.bytes = d_bytes;
+    A.offsets = d_offsets;
+    A.n_docs = n_docs;
+    A.n_bytes = n_bytes;
+    A.n_tiles = n_tiles;
+    A.ids_out = d_ids_out;
+    A.ids_cap = ids_cap;
+    A.out_offsets = d_out_offsets;
+    A.status = d_status;
+    A.err = d_err ? d_err : c->w_err.p;
+
+    c->ev_valid = false;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
+    HIP_TRY(hipMemsetAsync(A.err, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(W.counters, 0, 16, s));
+    if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
+    if (n_tiles == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_offsets, 0, (size_t)(n_docs + 1) * 8, s));
+        if (c->timing) {
+            HIP_TRY(hipEventRecord(c->ev[1], s));
+            HIP_TRY(hipEventRecord(c->ev[2], s));
+            HIP_TRY(hipEventRecord(c->ev[3], s));
+            c->ev_valid = true;
+        }
+        return HUTK_OK;
+    }
+    launch_pre(A, W, s);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
+    launch_tiles(c->dt, A, W, s);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    launch_exceptions(c->dt, A, W, s);
+    launch_scan(A, W, s);
+    launch_gather(A, W, s);
+    launch_doc_offsets(A, W, s);
+    HIP_TRY(hipGetLastError());
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev[3], s));
+        c->ev_valid = true;
+    }
+    return HUTK_OK;
+}
+
+int hutk_last_timing(hutk_ctx* c, float* ms_tile_kernel, float* ms_total) {
+    if (!c || !c->ev_valid) return set_err(HUTK_E_ARG, "no timed call yet");
+    HIP_TRY(hipEventSynchronize(c->ev[3]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[0], c->ev[3]));
+    if (ms_tile_kernel) *ms_tile_kernel = a;
+    if (ms_total) *ms_total = b;
+    return HUTK_OK;
+}
+
+int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                      int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
+    if (n_docs < 0 || !offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
+    if (offsets[0] != 0) return set_err(HUTK_E_ARG, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n_docs; i++)
+        if (offsets[i + 1] < offsets[i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
+    const int64_t n_bytes = offsets[n_docs];
+    if (n_bytes > 0 && (!bytes || !ids_out)) return set_err(HUTK_E_ARG, "bad argument");
+    const int64_t need = hutk_ids_capacity(c, n_bytes, n_docs) - 1;
+    if (ids_cap < need) return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->s_bytes.reserve((size_t)n_bytes + 64));
+    HIP_TRY(c->s_offsets.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->s_out_offsets.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->s_ids.reserve((size_t)need + 1));
+    HIP_TRY(c->s_status.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->w_err.reserve(1));
+    hipStream_t s = c->stream;
+    if (n_bytes) HIP_TRY(hipMemcpyAsync(c->s_bytes.p, bytes, (size_t)n_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->s_offsets.p, offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    int rc = hutk_encode_batch_device(c, c->s_bytes.p, c->s_offsets.p, n_docs, n_bytes, c->s_ids.p, need,
+                                      c->s_out_offsets.p, c->s_status.p, c->w_err.p, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out_offsets, c->s_out_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(&err, c->w_err.p, 4, hipMemcpyDeviceToHost, s));
+    if (status && n_docs)
+        HIP_TRY(hipMemcpyAsync(status, c->s_status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int64_t total = out_offsets[n_docs];
+    if (total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
+    if (total) HIP_TRY(hipMemcpy(ids_out, c->s_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    switch (err) {
+        case HUTK_OK: return HUTK_OK;
+        case HUTK_E_WORD_TOO_LARGE:
+            return set_err(err, "A single word in the input text is too large to be processed.");
+        case HUTK_E_NUL_BYTE: return set_err(err, "a document contains a 0x00 byte");
+        case HUTK_E_INVALID_UTF8: return set_err(err, "text is not valid UTF-8 (non-byte-encoder mode)");
+        case HUTK_E_CAPACITY: return set_err(err, "ids_cap too small");
+        default: return set_err(err, "device-side failure");
+    }
+}
+
+int hutk_encode(hutk_ctx* c, const uint8_t* text, int64_t len, int32_t* ids_out, int64_t ids_cap,
+                int64_t* n_ids, int32_t* status) {
+    if (!n_ids || len < 0) return set_err(HUTK_E_ARG, "bad argument");
+    int64_t offsets[2] = {0, len};
+    int64_t oo[2] = {0, 0};
+    int32_t st = 0;
+    int rc = hutk_encode_batch(c, text, offsets, 1, ids_out, ids_cap, oo, &st);
+    if (rc == HUTK_E_WORD_TOO_LARGE) {
+        // hutoken.encode() ignores the error and returns the ids produced before the
+        // offending word (lib.c:692-697): encode the text up to that word.  The cut
+        // position comes back through the exception record of the word.
+        int64_t cut = -1;
+        const uint32_t* cnt = c->w_counters.p;
+        uint32_t n_exc = 0;
+        if (hipMemcpy(&n_exc, cnt, 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<ExcRec> recs(n_exc);
+            if (n_exc && hipMemcpy(recs.data(), c->w_exc.p, n_exc * sizeof(ExcRec), hipMemcpyDeviceToHost) == hipSuccess)
+                for (auto& r : recs)
+                    if (r.tok_base < 0) {
+                        const int64_t at = -(r.tok_base + 1);
+                        if (cut < 0 || at < cut) cut = at;
+                    }
+        }
+        if (cut >= 0) {
+            offsets[1] = cut;
+            int rc2 = hutk_encode_batch(c, text, offsets, 1, ids_out, ids_cap, oo, nullptr);
+            if (rc2) return rc2;
+            *n_ids = oo[1];
+            if (status) *status = HUTK_DOC_WORD_TOO_LARGE;
+            g_err = "A single word in the input text is too large to be processed.";
+            return HUTK_E_WORD_TOO_LARGE;
+        }
+    }
+    *n_ids = oo[1];
+    if (status) *status = st;
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// hutk_device.h -- device-side structures and the launch interface between
+// hutk_api.cpp (host orchestration) and hutk_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "hutk_internal.h"
+
+namespace hutk {
+
+// ---- geometry of the tile kernel -----------------------------------------
+constexpr int TILE_BYTES = 2048;   // input bytes owned by one workgroup
+constexpr int TILE_THREADS = 256;  // 4 wavefronts
+constexpr int LOOKBACK = 16;       // bytes staged before the tile (classification needs <= 8)
+constexpr int HALO = 256;          // bytes staged after the tile (a word may end there)
+constexpr int TAIL = 16;           // look-ahead for the last halo positions
+constexpr int WINDOW = LOOKBACK + TILE_BYTES + HALO + TAIL;  // 2336 staged bytes
+constexpr int LANE_MAX_UNITS = 48;   // longest word a single lane merges
+constexpr int LANE_MAX_BYTES = 192;  // and its byte length (non-byte mode: up to 4 bytes/unit)
+constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units merge in LDS
+
+// per-position codes produced by the classifier (parser.c:24-183 restated as a
+// function of a +-3 byte neighbourhood)
+enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE = 4, C_WS = 5, C_BAD = 6 };
+
+struct DevTables {
+    const uint64_t* pair_slots;
+    uint32_t pair_mask, pair_shift;
+    const int32_t* sym_id;
+    uint32_t n_vocab_sym, n_sym;
+    const uint32_t* item_sym;    // [256]
+    const uint8_t* item_direct;  // [256]
+    const uint64_t* char_slots;
+    uint32_t char_mask, char_shift;
+    const uint32_t* prefix_syms;
+    int32_t n_prefix;
+    const int32_t* prefix_alone_ids;
+    int32_t n_prefix_alone;
+    int32_t is_byte_encoder, has_prefix, rank_is_sym, ident_ids;
+};
+
+// one word the tile kernel hands to the exception kernel
+struct ExcRec {
+    int64_t ws;        // global byte offset of the word
+    int64_t tok_base;  // its ids start at exc_tok[tok_base] (written by the exception kernel;
+                       // negative: the word was too large, -(offset in document)-1)
+    int32_t len;       // byte length, or -1 when the end lies beyond the staged window
+    uint32_t wpos;     // ids the tile emitted before this word (tile-local)
+    uint32_t cnt;      // ids of this word (written by the exception kernel)
+    uint32_t tile;
+};
+
+struct Workspace {
+    int32_t* run;         // [cap_bytes] dense id run of tile t at run[t*TILE_BYTES + first_word + k]
+    int32_t* exc_tok;     // [cap_bytes + pad] ids of exception words at their own byte offset (+ doc padding)
+    uint32_t* exc_sym;    // [cap_bytes + pad] symbol array of exception words too long for LDS
+    uint32_t* exc_mrg;    // [cap_bytes + pad] their pair array
+    uint32_t* tile_count;      // [n_tiles] ids per tile (dense run + exception words)
+    uint32_t* tile_dense;      // [n_tiles] ids in the dense run only
+    uint32_t* tile_run_start;  // [n_tiles] tile-local offset of the run (= first word start)
+    uint32_t* tile_exc_first;  // [n_tiles] index of the tile's first ExcRec
+    uint32_t* tile_nexc;       // [n_tiles]
+    int64_t* tile_first_doc;   // [n_tiles] first document whose offset is >= tile start - LOOKBACK
+    int64_t* tile_base;        // [n_tiles + 1] exclusive scan of tile_count
+    uint32_t* doc_tile_pos;    // [n_docs + 1] ids the owning tile emits before the document start
+    ExcRec* exc;               // [cap_exc]
+    uint32_t* counters;        // [0] exception total, [1] exception work cursor
+    int64_t cap_exc;
+    int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
+};
+
+struct BatchArgs {
+    const uint8_t* bytes;
+    const int64_t* offsets;
+    int64_t n_docs, n_bytes, n_tiles;
+    int32_t* ids_out;
+    int64_t ids_cap;
+    int64_t* out_offsets;
+    int32_t* status;  // may be null
+    int32_t* err;     // never null (workspace word when the caller passes none)
+};
+
+// hutk_kernels.hip
+void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_gather(const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s);
+// one-off at context creation: merge a symbol sequence on the device, return ids
+void launch_bpe_symbols(const DevTables& t, const uint32_t* d_syms, int n, int32_t* d_ids_out,
+                        int32_t* d_n_out, hipStream_t s);
+
+}  // namespace hutk

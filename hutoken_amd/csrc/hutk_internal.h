@@ -1,0 +1,88 @@
+// hutk_internal.h -- shared between the host loader, the C-ABI and the kernels.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "hutoken_amd.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define HUTK_HD __host__ __device__ __forceinline__
+#else
+#define HUTK_HD inline
+#endif
+
+namespace hutk {
+
+// ---- symbol space -------------------------------------------------------
+// Every byte string that can be a live token during a merge is a "symbol":
+// the distinct vocabulary keys (numbered in ascending id order) followed by the
+// initial units that are not keys ("pseudo" symbols, id -1).  Symbols are 20-bit.
+constexpr uint32_t SYM_BITS = 20;
+constexpr uint32_t SYM_UNK = (1u << SYM_BITS) - 1;  // unit that is no symbol: never merges, id -1
+constexpr uint32_t SYM_NONE = 0xFFFFFFFFu;          // "this pair has no rank"
+constexpr uint64_t SLOT_EMPTY = ~0ull;
+
+// pair table slot: [left:20][right:20][merged:20] in the low 60 bits
+static inline uint64_t pair_slot(uint32_t l, uint32_t r, uint32_t m) {
+    return ((uint64_t)l << 40) | ((uint64_t)r << 20) | m;
+}
+
+// The same mixing function on host (table build) and device (lookup).
+HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) {
+    uint32_t h = l * 0x9E3779B1u ^ (r * 0x85EBCA77u + 0x165667B1u);
+    h ^= h >> 15;
+    return h * 0x2C1B3C6Du;
+}
+HUTK_HD uint32_t char_hash(uint32_t packed) {
+    uint32_t h = packed * 0x9E3779B1u;
+    h ^= h >> 16;
+    return h * 0x85EBCA6Bu;
+}
+
+// reference limit: 64 * word length must fit the 16 MiB arena (core.c:27-28, 402-407)
+constexpr int64_t MAX_WORD_BYTES = 262144;
+
+struct Tables {
+    // vocabulary facts
+    int64_t n_keys = 0;         // distinct keys loaded (duplicates collapsed, last id wins)
+    uint32_t n_vocab_sym = 0;   // keys with id != -1
+    uint32_t n_sym = 0;         // + pseudo symbols
+    bool rank_is_sym = false;   // ids strictly increase with the symbol index
+    bool ident_ids = false;     // id(sym) == sym for every vocabulary symbol
+    std::vector<int32_t> sym_id;  // [n_sym]
+
+    // (left, right) -> merged symbol, open addressing, linear probing
+    std::vector<uint64_t> pair_slots;
+    uint32_t pair_mask = 0;
+    uint32_t pair_shift = 0;  // 32 - log2(capacity)
+    int64_t n_pairs = 0;
+
+    // initial symbol of a source item
+    //   byte-encoder mode: item = input byte
+    //   otherwise:         item = UTF-8 character, indexed by its lead byte when
+    //                      the lead byte has a replacement or is ASCII
+    uint32_t item_sym[256];
+    uint8_t item_direct[256];  // 1: item_sym valid for this (lead) byte
+    // non-byte mode: multi-byte character (packed little-endian) -> symbol
+    std::vector<uint64_t> char_slots;  // [packed:32][sym:32], SLOT_EMPTY
+    uint32_t char_mask = 0;
+    uint32_t char_shift = 0;
+
+    bool is_byte_encoder = false;
+    bool has_prefix = false;
+    std::vector<uint32_t> prefix_syms;        // units of the prefix when it is prepended to a word
+    std::vector<uint32_t> prefix_alone_syms;  // units of the prefix encoded as its own word
+};
+
+struct LoadError {
+    int code = HUTK_OK;
+    std::string msg;
+};
+
+// hutk_loader.cpp: parse both files with the reference's quirks and build Tables.
+LoadError load_tables(const char* vocab_path, const char* special_path, const char* prefix,
+                      bool is_byte_encoder, Tables& out);
+
+}  // namespace hutk

@@ -1,0 +1,378 @@
+// hutk_loader.cpp -- host side of hutk_ctx_create: reads huToken's vocab and
+// special-character files with the reference's observable quirks and turns them
+// into the device tables of hutk_internal.h.
+//
+// Reference behaviour followed here (paths into the reference tree):
+//   vocab file      src/lib.c:243-388, src/helper.c:82-128
+//   special file    src/lib.c:460-571
+//   unit rule       src/core.c:35-55 (literal "<0x..>" or one UTF-8 character,
+//                   src/pretokenizer.c:14-28)
+//   pretokenizer    src/pretokenizer.c:102-168
+//   rank of a pair  src/core.c:700-722: the vocabulary id of the concatenation
+#include <algorithm>
+#include <cerrno>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hutk_internal.h"
+
+namespace hutk {
+namespace {
+
+struct FileCloser {
+    void operator()(FILE* f) const {
+        if (f) fclose(f);
+    }
+};
+using File = std::unique_ptr<FILE, FileCloser>;
+
+LoadError fail(int code, const char* msg) { return LoadError{code, msg}; }
+
+// helper.c:82-128: "0x" + two characters handed to strtol(.., 16); anything else
+// is skipped.  false when more than 2047 bytes would be produced.
+bool hex_field_to_bytes(const char* s, const char* end, std::string& out) {
+    out.clear();
+    while (s < end) {
+        if (s[0] == '0' && s + 1 < end && s[1] == 'x') {
+            s += 2;
+            if (s < end && s + 1 < end) {
+                const char two[3] = {s[0], s[1], 0};
+                if (out.size() >= 2047) return false;
+                out.push_back((char)(unsigned)strtol(two, nullptr, 16));
+            }
+            s += 2;
+        } else {
+            ++s;
+        }
+    }
+    return true;
+}
+
+LoadError read_vocab(const char* path, std::unordered_map<std::string, int32_t>& vocab) {
+    File f(fopen(path, "rb"));
+    if (!f) return fail(HUTK_E_FILE_NOT_FOUND, "Could not open vocab file.");
+    std::string data;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f.get())) > 0) data.append(buf, got);
+    size_t pos = 0, lines = 0;
+    std::string key;
+    while (pos < data.size()) {
+        const void* nl = memchr(data.data() + pos, '\n', data.size() - pos);
+        if (!nl) break;  // lib.c:264-289: an unterminated final line is dropped silently
+        size_t eol = (const char*)nl - data.data();
+        // C-string view of the line: it ends at an embedded NUL if there is one
+        std::string line(data.data() + pos, eol + 1 - pos);
+        line.resize(strlen(line.c_str()));
+        pos = eol + 1;
+        const char* sep = strstr(line.c_str(), " == ");
+        if (!sep) return fail(HUTK_E_VALUE, "Invalid format in vocab file.");
+        const char* vs = sep + 4;
+        char* endp = nullptr;
+        errno = 0;
+        long v = strtol(vs, &endp, 10);
+        if (endp == vs)
+            return fail(HUTK_E_VALUE, "Invalid vocab format: could not parse integer value.");
+        if (errno == ERANGE || v > INT_MAX || v < INT_MIN)
+            return fail(HUTK_E_VALUE, "Integer value in vocab file is out of range.");
+        bool ok = hex_field_to_bytes(line.c_str(), sep, key);
+        // strdup(): the key ends at its first 0x00; an empty key is an error (lib.c:345-357)
+        if (ok) key.resize(strlen(key.c_str()));
+        if (!ok || key.empty()) return fail(HUTK_E_VALUE, "Failed to convert hex string to ASCII.");
+        vocab[key] = (int32_t)v;  // a repeated key keeps its last id (hashmap.c:208-214)
+        ++lines;
+    }
+    if (lines == 0) return fail(HUTK_E_VALUE, "Vocab file is empty.");
+    return {};
+}
+
+LoadError read_special(const char* path, std::string special[256], bool has[256]) {
+    File f(fopen(path, "r"));
+    if (!f) return fail(HUTK_E_FILE_NOT_FOUND, "Could not open special characters file.");
+    char buf[32];  // lib.c:483: records are 31-character fgets() chunks
+    while (fgets(buf, sizeof buf, f.get())) {
+        const char* sep = strstr(buf, " == ");
+        if (!sep) return fail(HUTK_E_VALUE, "Invalid format in special character file.");
+        char* endp = nullptr;
+        errno = 0;
+        long idx = strtol(buf, &endp, 10);
+        if (endp == buf)
+            return fail(HUTK_E_VALUE, "Invalid vocab format: could not parse integer value.");
+        // lib.c:516 lets 256 through and then writes out of bounds; rejected here
+        if (errno == ERANGE || idx > 255 || idx < 0)
+            return fail(HUTK_E_VALUE, "Integer value in vocab file is out of range.");
+        const char* vs = sep + 4;
+        size_t vlen = strlen(vs);
+        // the chunk's last character is dropped whatever it is (lib.c:527-531)
+        if (vlen < 2) return fail(HUTK_E_VALUE, "Failed to convert hex string to ASCII.");
+        special[idx].assign(vs, vlen - 1);
+        has[idx] = true;
+    }
+    return {};
+}
+
+int lead_len(unsigned char b) {  // pretokenizer.c:14-28
+    if ((b & 0x80) == 0x00) return 1;
+    if ((b & 0xE0) == 0xC0) return 2;
+    if ((b & 0xF0) == 0xE0) return 3;
+    if ((b & 0xF8) == 0xF0) return 4;
+    return 1;
+}
+
+bool is_hex(unsigned char c) {
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F');
+}
+
+// core.c:35-47 on a bounded string.  Returns the literal's length, 0 when s does
+// not start one, and sets *dangling when s ran out while still matching.
+size_t hex_literal_len(const std::string& s, size_t p, bool* dangling) {
+    *dangling = false;
+    static const char pat0[] = "<0";
+    for (size_t k = 0; k < 2; k++) {
+        if (p + k >= s.size()) { *dangling = true; return 0; }
+        if (s[p + k] != pat0[k]) return 0;
+    }
+    if (p + 2 >= s.size()) { *dangling = true; return 0; }
+    if (s[p + 2] != 'x' && s[p + 2] != 'X') return 0;
+    size_t q = p + 3;
+    while (q < s.size() && is_hex((unsigned char)s[q])) q++;
+    if (q >= s.size()) { *dangling = true; return 0; }
+    return s[q] == '>' ? q - p + 1 : 0;
+}
+
+// Splits s into units.  false when a unit would run past the end of s or when s
+// ends in a proper prefix of a "<0x..>" literal: in both cases the reference's
+// split of the word would depend on the NEXT item, which the per-item device
+// tables cannot express.
+bool split_units(const std::string& s, bool hex_units, std::vector<std::string>& out) {
+    out.clear();
+    size_t p = 0;
+    while (p < s.size()) {
+        size_t l = 0;
+        if (hex_units) {
+            bool dangling = false;
+            l = hex_literal_len(s, p, &dangling);
+            if (dangling) return false;
+        }
+        if (!l) l = (size_t)lead_len((unsigned char)s[p]);
+        if (p + l > s.size()) return false;
+        out.push_back(s.substr(p, l));
+        p += l;
+    }
+    // a '<' later in s must not leave a dangling literal prefix either
+    if (hex_units)
+        for (size_t q = 0; q < s.size(); q++)
+            if (s[q] == '<') {
+                bool dangling = false;
+                (void)hex_literal_len(s, q, &dangling);
+                if (dangling) return false;
+            }
+    return true;
+}
+
+bool unit_shaped(const std::string& s) {
+    if (s.empty()) return false;
+    bool dangling = false;
+    size_t l = hex_literal_len(s, 0, &dangling);
+    if (l == s.size()) return true;
+    return (size_t)lead_len((unsigned char)s[0]) == s.size();
+}
+
+uint32_t pack_char(const std::string& s) {
+    uint32_t v = 0;
+    for (size_t i = 0; i < s.size() && i < 4; i++) v |= (uint32_t)(unsigned char)s[i] << (8 * i);
+    return v;
+}
+
+uint32_t pow2_at_least(uint64_t n) {
+    uint32_t c = 16;
+    while (c < n) c <<= 1;
+    return c;
+}
+
+}  // namespace
+
+LoadError load_tables(const char* vocab_path, const char* special_path, const char* prefix,
+                      bool is_byte_encoder, Tables& T) {
+    std::unordered_map<std::string, int32_t> vocab;
+    LoadError e = read_vocab(vocab_path, vocab);
+    if (e.code) return e;
+    std::string special[256];
+    bool has_special[256] = {false};
+    e = read_special(special_path, special, has_special);
+    if (e.code) return e;
+
+    T = Tables();
+    T.is_byte_encoder = is_byte_encoder;
+    T.n_keys = (int64_t)vocab.size();
+
+    // ---- symbols: keys in ascending id order (an id of -1 is "absent",
+    // core.c:100,155,168,205-207) ----
+    std::vector<std::pair<int32_t, const std::string*>> order;
+    order.reserve(vocab.size());
+    for (auto& kv : vocab)
+        if (kv.second != -1) order.push_back({kv.second, &kv.first});
+    std::sort(order.begin(), order.end(), [](auto& a, auto& b) {
+        return a.first != b.first ? a.first < b.first : *a.second < *b.second;
+    });
+    std::unordered_map<std::string, uint32_t> sym_of;
+    sym_of.reserve(order.size() * 2);
+    T.sym_id.reserve(order.size() + 512);
+    T.rank_is_sym = true;
+    T.ident_ids = true;
+    for (size_t i = 0; i < order.size(); i++) {
+        sym_of.emplace(*order[i].second, (uint32_t)i);
+        T.sym_id.push_back(order[i].first);
+        if (i && order[i].first == order[i - 1].first) T.rank_is_sym = false;
+        if (order[i].first != (int32_t)i) T.ident_ids = false;
+    }
+    T.n_vocab_sym = (uint32_t)order.size();
+    auto pseudo = [&](const std::string& s) -> uint32_t {
+        auto it = sym_of.find(s);
+        if (it != sym_of.end()) return it->second;
+        uint32_t id = (uint32_t)T.sym_id.size();
+        sym_of.emplace(s, id);
+        T.sym_id.push_back(-1);
+        return id;
+    };
+
+    // ---- items -> initial symbols ----
+    std::vector<std::string> units;
+    const bool raw_lt_possible = !has_special[(unsigned char)'<'];
+    for (int b = 1; b < 256; b++) {
+        T.item_sym[b] = SYM_UNK;
+        T.item_direct[b] = 0;
+        // outside byte-encoder mode an item is a whole character indexed by its lead
+        // byte; 0x80-0xBF and 0xF8-0xFF never lead a valid character, and text that
+        // is not valid UTF-8 is rejected there, so their entries are inert
+        const bool never_leads = !is_byte_encoder && ((b >= 0x80 && b < 0xC0) || b >= 0xF8);
+        if (never_leads) continue;
+        std::string s;
+        if (has_special[b]) {
+            s = special[b];
+            if (!split_units(s, true, units))
+                return fail(HUTK_E_UNSUPPORTED,
+                            "special-character replacement is not a whole number of units");
+            if (raw_lt_possible && s[0] == '0')
+                return fail(HUTK_E_UNSUPPORTED,
+                            "special-character replacement starting with '0' could complete a "
+                            "\"<0x..>\" literal begun by a raw '<'");
+            if (units.size() != 1)
+                return fail(HUTK_E_UNSUPPORTED,
+                            "special-character replacement with more than one unit");
+        } else if (is_byte_encoder && b >= 0x80) {  // pretokenizer.c:138-141
+            s.push_back((char)(0xC0 | (b >> 6)));
+            s.push_back((char)(0x80 | (b & 0x3F)));
+        } else if (b < 0x80) {
+            s.push_back((char)b);
+        } else {
+            continue;  // multi-byte character without replacement: char table
+        }
+        // a unit that is no key still gets a symbol of its own (id -1): it can be
+        // one half of a longer key (core.c:700-722 looks the concatenation up)
+        T.item_sym[b] = pseudo(s);
+        T.item_direct[b] = 1;
+    }
+    T.item_sym[0] = SYM_UNK;
+    T.item_direct[0] = 1;
+
+    // ---- prefix (core.c:421-451) ----
+    if (prefix && prefix[0]) {
+        T.has_prefix = true;
+        std::string p(prefix);
+        if (!split_units(p, true, units))
+            return fail(HUTK_E_UNSUPPORTED, "prefix is not a whole number of units");
+        for (auto& u : units) T.prefix_syms.push_back(pseudo(u));
+        // the prefix encoded as a word of its own goes through the pretokenizer
+        // (special characters apply) and is split by UTF-8 length only
+        std::string enc;
+        for (size_t i = 0; i < p.size();) {
+            unsigned char b = (unsigned char)p[i];
+            size_t cl = is_byte_encoder ? 1 : (size_t)lead_len(b);
+            if (i + cl > p.size()) return fail(HUTK_E_UNSUPPORTED, "prefix is not valid UTF-8");
+            if (has_special[b]) enc += special[b];
+            else if (is_byte_encoder && b >= 0x80) {
+                enc.push_back((char)(0xC0 | (b >> 6)));
+                enc.push_back((char)(0x80 | (b & 0x3F)));
+            } else enc.append(p, i, cl);
+            i += cl;
+        }
+        if (!split_units(enc, false, units))
+            return fail(HUTK_E_UNSUPPORTED, "encoded prefix is not a whole number of units");
+        for (auto& u : units) T.prefix_alone_syms.push_back(pseudo(u));
+    }
+
+    // ---- pairs: every split of every key whose halves are symbols ----
+    std::vector<uint64_t> entries;
+    entries.reserve(order.size() * 3);
+    for (size_t i = 0; i < order.size(); i++) {
+        const std::string& k = *order[i].second;
+        for (size_t s = 1; s < k.size(); s++) {
+            std::string l = k.substr(0, s), r = k.substr(s);
+            uint32_t ls, rs;
+            // outside byte-encoder mode a unit that is no key (an unknown character)
+            // can still be one half of a key: give it a symbol
+            auto li = sym_of.find(l);
+            if (li != sym_of.end()) ls = li->second;
+            else if (!is_byte_encoder && unit_shaped(l)) ls = pseudo(l);
+            else continue;
+            auto ri = sym_of.find(r);
+            if (ri != sym_of.end()) rs = ri->second;
+            else if (!is_byte_encoder && unit_shaped(r)) rs = pseudo(r);
+            else continue;
+            entries.push_back(pair_slot(ls, rs, (uint32_t)i));
+        }
+    }
+    T.n_sym = (uint32_t)T.sym_id.size();
+    if (T.n_sym >= SYM_UNK)
+        return fail(HUTK_E_UNSUPPORTED, "vocabulary too large for 20-bit symbols");
+    T.n_pairs = (int64_t)entries.size();
+    {
+        uint32_t cap = pow2_at_least(entries.size() * 2 + 16);
+        uint32_t lg = 0;
+        while ((1u << lg) < cap) lg++;
+        T.pair_mask = cap - 1;
+        T.pair_shift = 32 - lg;
+        T.pair_slots.assign(cap, SLOT_EMPTY);
+        for (uint64_t en : entries) {
+            uint32_t l = (uint32_t)(en >> 40), r = (uint32_t)((en >> 20) & 0xFFFFF);
+            uint32_t h = pair_hash(l, r) >> T.pair_shift;
+            while (T.pair_slots[h] != SLOT_EMPTY) h = (h + 1) & T.pair_mask;
+            T.pair_slots[h] = en;
+        }
+    }
+
+    // ---- non-byte mode: multi-byte character -> symbol ----
+    if (!is_byte_encoder) {
+        std::vector<std::pair<uint32_t, uint32_t>> chars;
+        for (auto& kv : sym_of) {
+            const std::string& s = kv.first;
+            if (s.size() >= 2 && s.size() <= 4 && (size_t)lead_len((unsigned char)s[0]) == s.size())
+                chars.push_back({pack_char(s), kv.second});
+        }
+        uint32_t cap = pow2_at_least(chars.size() * 2 + 16);
+        uint32_t lg = 0;
+        while ((1u << lg) < cap) lg++;
+        T.char_mask = cap - 1;
+        T.char_shift = 32 - lg;
+        T.char_slots.assign(cap, SLOT_EMPTY);
+        for (auto& c : chars) {
+            uint32_t h = char_hash(c.first) >> T.char_shift;
+            while (T.char_slots[h] != SLOT_EMPTY) h = (h + 1) & T.char_mask;
+            T.char_slots[h] = ((uint64_t)c.first << 32) | c.second;
+        }
+    } else {
+        T.char_slots.assign(16, SLOT_EMPTY);
+        T.char_mask = 15;
+        T.char_shift = 28;
+    }
+    return {};
+}
+
+}  // namespace hutk

@@ -1,0 +1,124 @@
+/*
+ * hutoken_amd.h -- C ABI of the MI355X-native batch BPE encode path.
+ *
+ * This is the drop-in boundary for huToken's encode direction.  Each entry point
+ * names the reference interface it replaces (paths are into the reference tree,
+ * matyasosvath/hutoken @ 2025-09-05).  Plain pointers and sizes only; no Python,
+ * torch or HIP types appear in a signature (a HIP stream is passed as void*).
+ * INTEGRATION.md shows the binding a maintainer would add to src/lib.c.
+ *
+ * All results are bit-exact with the reference's string-keyed path
+ * (src/core.c:66-209, 339-511) on the same inputs.  There is no CPU fallback:
+ * every encode call runs on the GPU or fails with HUTK_E_DEVICE.
+ */
+#ifndef HUTOKEN_AMD_H
+#define HUTOKEN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hutk_ctx hutk_ctx;
+
+/* return codes; the comment names the Python exception the reference raises in
+ * the same situation (src/lib.c) */
+enum {
+    HUTK_OK = 0,
+    HUTK_E_FILE_NOT_FOUND = 1,  /* FileNotFoundError (lib.c:243-250, 460-469) */
+    HUTK_E_VALUE = 2,           /* ValueError        (lib.c:295-388, 487-543) */
+    HUTK_E_MEMORY = 3,          /* MemoryError */
+    HUTK_E_ARG = 4,             /* TypeError / bad argument */
+    HUTK_E_DEVICE = 5,          /* no GPU, HIP failure: the path fails loudly */
+    HUTK_E_UNSUPPORTED = 6,     /* a file shape the device tables cannot hold */
+    HUTK_E_CAPACITY = 7,        /* ids_cap below hutk_ids_capacity() */
+    HUTK_E_NUL_BYTE = 8,        /* a 0x00 byte inside a document */
+    HUTK_E_WORD_TOO_LARGE = 9,  /* RuntimeError (core.c:402-407, lib.c:796-808) */
+    HUTK_E_INVALID_UTF8 = 10    /* non-byte-encoder mode only; the reference's
+                                   behaviour there is undefined */
+};
+
+/* per-document status values written to status[] */
+enum {
+    HUTK_DOC_OK = 0,
+    HUTK_DOC_WORD_TOO_LARGE = 1, /* ids hold the tokens BEFORE the offending word,
+                                    as hutoken.encode() returns them (lib.c:692-697) */
+    HUTK_DOC_INVALID_UTF8 = 2
+};
+
+/* Replaces _hutoken.initialize(vocab_file_path, special_file_path, prefix,
+ * is_byte_encoder, ...) for the encode direction: src/lib.c:185-571
+ * (initialize_context 128-183, vocab loader 243-388, special-character loader
+ * 460-571) and struct EncodeContext (include/hutoken/taskqueue.h:16-25).
+ * The decode tables, the AC automaton, the regex pattern and the merges file are
+ * outside this path.  `device` is a HIP device ordinal, or -1 for the current
+ * device.  On failure *out is NULL and hutk_last_error() holds the message. */
+int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_path,
+                    const char* prefix, int is_byte_encoder, int device);
+
+/* The reference never frees its contexts (lib.c:129-155); this one can be. */
+void hutk_ctx_destroy(hutk_ctx* ctx);
+
+/* Message of the last failure on this thread (static storage, never NULL). */
+const char* hutk_last_error(void);
+
+/* Worst-case number of ids for a batch of n_bytes bytes in n_docs documents
+ * (#ids <= #units <= bytes + prefix units per document). */
+int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs);
+
+/* Replaces the worker pool of p_batch_encode, src/lib.c:779-794, i.e. N threads
+ * calling `void encode(struct EncodeTask*)` (include/hutoken/core.h:11,
+ * src/core.c:339-511) once per document.  Batch-granular: documents are packed
+ * back to back in `bytes`; document i is bytes[offsets[i] .. offsets[i+1]).
+ * Host buffers in, host buffers out (the copies over PCIe are inside the call).
+ *   ids_out      int32[ids_cap], ids_cap >= hutk_ids_capacity(...)
+ *   out_offsets  int64[n_docs+1]; document i's ids are
+ *                ids_out[out_offsets[i] .. out_offsets[i+1])
+ *   status       int32[n_docs] (HUTK_DOC_*), may be NULL
+ * Returns HUTK_OK, or the first error (HUTK_E_WORD_TOO_LARGE mirrors
+ * lib.c:796-808: the reference discards the whole batch; here the outputs stay
+ * valid and status[] says which documents were cut). */
+int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offsets,
+                      int64_t n_docs, int32_t* ids_out, int64_t ids_cap,
+                      int64_t* out_offsets, int32_t* status);
+
+/* Same computation with every buffer already resident in device memory (the
+ * form bench.py times and a GPU data loader would call).  n_bytes must equal
+ * offsets[n_docs] (the host needs it to size the launch without a sync).
+ * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and
+ * the call returns without synchronising; d_err receives the first device-side
+ * error code (HUTK_OK when none) and may be NULL.  d_bytes must be 16-byte
+ * aligned. */
+int hutk_encode_batch_device(hutk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets,
+                             int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out,
+                             int64_t ids_cap, int64_t* d_out_offsets, int32_t* d_status,
+                             int32_t* d_err, void* hip_stream);
+
+/* Replaces p_encode, src/lib.c:668-720 (one document on the calling thread). */
+int hutk_encode(hutk_ctx* ctx, const uint8_t* text, int64_t len, int32_t* ids_out,
+                int64_t ids_cap, int64_t* n_ids, int32_t* status);
+
+/* Introspection (tests, bench). */
+int64_t hutk_vocab_size(const hutk_ctx* ctx);      /* distinct keys loaded */
+int64_t hutk_pair_table_entries(const hutk_ctx* ctx);
+int hutk_device_ordinal(const hutk_ctx* ctx);
+/* out8: distinct keys, vocabulary symbols, symbols, pair entries, pair slots,
+ * rank_is_sym, ident_ids, prefix units.  Passing device = -2 to hutk_ctx_create
+ * builds a host-only context (tables, no GPU) for this kind of inspection;
+ * encode calls on it fail with HUTK_E_DEVICE. */
+int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8);
+
+/* Device time of the most recent hutk_encode_batch_device/hutk_encode_batch call,
+ * from HIP events recorded on the launch stream: the dominant kernel
+ * ("encode tiles") and the whole enqueue.  Synchronises on those events. */
+int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
+
+/* Per-call profiling events cost a little; they are on by default. */
+void hutk_set_timing(hutk_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HUTOKEN_AMD_H */

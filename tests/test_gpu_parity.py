@@ -1,0 +1,185 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bit-exact ids and offsets are required (integer work, no
+tolerance).  Every test here needs a real MI355X."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(vp, sp, prefix, is_byte):
+    from hutoken_amd import _capi
+    return _capi.Context(vp, sp, prefix, is_byte)
+
+
+def _compare(ctx, orc, docs, tag=""):
+    """docs: list[bytes] without 0x00."""
+    from oracle import oracle as O
+    data, offs = O.pack(docs)
+    ids_o, oo_o, st_o = orc.encode_packed(data, offs, num_threads=4)
+    ids_g, oo_g, st_g, rc = ctx.encode_packed(data, offs)
+    assert rc == 0, f"{tag}: rc={rc}"
+    if not np.array_equal(oo_o, oo_g):
+        bad = int(np.nonzero(oo_o != oo_g)[0][0])
+        d = max(bad - 1, 0)
+        raise AssertionError(
+            f"{tag}: out_offsets differ first at {bad}; doc {d}={docs[d]!r}\n"
+            f" oracle={ids_o[oo_o[d]:oo_o[d + 1]].tolist()}\n gpu   ={ids_g[oo_g[d]:oo_g[d + 1]].tolist()}")
+    if not np.array_equal(ids_o, ids_g):
+        k = int(np.nonzero(ids_o != ids_g)[0][0])
+        d = int(np.searchsorted(oo_o, k, side="right") - 1)
+        raise AssertionError(
+            f"{tag}: ids differ first at {k} (doc {d}={docs[d]!r})\n"
+            f" oracle={ids_o[oo_o[d]:oo_o[d + 1]].tolist()}\n gpu   ={ids_g[oo_g[d]:oo_g[d + 1]].tolist()}")
+    assert (st_g == 0).all()
+
+
+@pytest.fixture(scope="module")
+def small_byte(tmp_path_factory, oracle_mod):
+    tmp = tmp_path_factory.mktemp("bv")
+    out = []
+    for seed, proper, dup in [(1, True, False), (2, False, False), (3, True, True)]:
+        ents, sp = H.random_byte_vocab(seed, n_merges=500, proper=proper, dup_ids=dup)
+        vp, spath = H.write_vocab(tmp, f"b{seed}", ents, sp)
+        out.append((_ctx(vp, spath, None, True), oracle_mod.Oracle(vp, spath, None, True)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def small_char(tmp_path_factory, oracle_mod):
+    tmp = tmp_path_factory.mktemp("cv")
+    out = []
+    for seed, drop in [(1, ""), (2, "qző漢")]:
+        ents, sp = H.random_char_vocab(seed, n_merges=500, drop_chars=drop)
+        vp, spath = H.write_vocab(tmp, f"c{seed}", ents, sp)
+        out.append((_ctx(vp, spath, "▁", False), oracle_mod.Oracle(vp, spath, "▁", False)))
+    return out
+
+
+def test_hello_world(small_byte):
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, [b"hello world"], "hello")
+
+
+def test_edge_documents(small_byte):
+    docs = [b"", b" ", b"  ", b"a", b" a", b"  a", b"a  b", b"a   b   c", b"aaaaa", b"\t\n\r\f\v", b"word ",
+            b"", b"", "árvíztűrő tükörfúrógép".encode(), " First Second".encode(), "€".encode(),
+            "😂".encode(), b"word123", b"123.!", b".!word", b"A  B   C", b"Hello world 123. End!", b"x \ta",
+            "a b".encode(), "ab".encode(), b"", b"z"]
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, docs, "edge")
+        _compare(ctx, orc, [b""], "one-empty")
+        _compare(ctx, orc, [b"", b"", b""], "all-empty")
+
+
+def test_random_text_byte_mode(small_byte):
+    for k, (ctx, orc) in enumerate(small_byte):
+        rng = random.Random(100 + k)
+        docs = [H.random_text(rng, max_words=40).encode("utf-8") for _ in range(3000)]
+        _compare(ctx, orc, docs, f"text{k}")
+
+
+def test_arbitrary_bytes_byte_mode(small_byte):
+    """Truncated / invalid / overlong UTF-8: defined for the byte encoder."""
+    for k, (ctx, orc) in enumerate(small_byte):
+        rng = random.Random(200 + k)
+        docs = [H.random_bytes_text(rng, rng.randint(0, 60)) for _ in range(3000)]
+        _compare(ctx, orc, docs, f"bytes{k}")
+
+
+def test_document_boundaries_inside_characters(small_byte):
+    """Ragged packing: documents end in the middle of multi-byte sequences and
+    tiles end in the middle of words."""
+    ctx, orc = small_byte[0]
+    rng = random.Random(7)
+    blob = "".join(H.random_text(rng, max_words=30) for _ in range(400)).encode("utf-8").replace(b"\0", b"")
+    docs, i = [], 0
+    while i < len(blob):
+        n = rng.choice([0, 1, 2, 3, 5, 17, 64, 300, 2047, 2048, 2049, 5000])
+        docs.append(blob[i:i + n])
+        i += n
+    _compare(ctx, orc, docs, "ragged")
+
+
+def test_long_words_exception_path(small_byte):
+    """Words beyond one lane's capacity (48 units), beyond the staged window,
+    and beyond the LDS capacity of the exception kernel (1024 units)."""
+    rng = random.Random(11)
+    docs = []
+    for n in [47, 48, 49, 50, 64, 100, 191, 192, 193, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 1500, 3000, 9000]:
+        docs.append(bytes(rng.choice(b"etaoinshr") for _ in range(n)))
+        docs.append(b"pre " + bytes(rng.choice(b"etaoin") for _ in range(n)) + b" post")
+        docs.append(("漢" * (n // 3 + 1)).encode("utf-8"))
+    docs.append(b"a" * 5000 + b" " + b"b" * 2100)
+    docs.append(b" " * 3000)
+    docs.append(b"1" * 2500 + b"x" * 2500)
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, docs, "long")
+
+
+def test_random_text_char_mode_with_prefix(small_char):
+    for k, (ctx, orc) in enumerate(small_char):
+        rng = random.Random(300 + k)
+        docs = [H.random_text(rng, max_words=40).encode("utf-8") for _ in range(3000)]
+        docs += [b"", b" ", b"a", b" a", "漢".encode(), b"\n", b"  x"]
+        _compare(ctx, orc, docs, f"char{k}")
+
+
+def test_long_words_char_mode(small_char):
+    rng = random.Random(13)
+    docs = []
+    for n in [47, 48, 49, 100, 300, 1023, 1024, 1025, 3000]:
+        docs.append("".join(rng.choice("etaoinőű") for _ in range(n)).encode("utf-8"))
+        docs.append((" x " + "".join(rng.choice("漢字aé") for _ in range(n)) + " y").encode("utf-8"))
+    for ctx, orc in small_char:
+        _compare(ctx, orc, docs, "charlong")
+
+
+def test_vg_vocab_on_corpora(vg_files, oracle_mod):
+    from hutoken_amd import synth
+    vp, sp, kw = vg_files
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    for name, n in [("C2", 3000), ("C3", 3000), ("C5", 1000)]:
+        data, offs = synth.corpus(name, n)
+        ids_o, oo_o, _ = orc.encode_packed(data, offs, num_threads=8)
+        ids_g, oo_g, st, rc = ctx.encode_packed(data, offs)
+        assert rc == 0
+        assert np.array_equal(oo_o, oo_g), name
+        assert np.array_equal(ids_o, ids_g), name
+
+
+def test_vl_vocab_on_corpora(vl_files, oracle_mod):
+    from hutoken_amd import synth
+    vp, sp, kw = vl_files
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    for name, n in [("C5", 3000), ("C3", 2000)]:
+        data, offs = synth.corpus(name, n)
+        ids_o, oo_o, _ = orc.encode_packed(data, offs, num_threads=8)
+        ids_g, oo_g, st, rc = ctx.encode_packed(data, offs)
+        assert rc == 0
+        assert np.array_equal(oo_o, oo_g), name
+        assert np.array_equal(ids_o, ids_g), name
+
+
+def test_python_surface(vg_files, oracle_mod):
+    import hutoken_amd as hutoken
+    vp, sp, kw = vg_files
+    hutoken.initialize(vp, sp, **kw)
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    assert hutoken.encode("hello world") == orc.encode("hello world")
+    assert hutoken.encode("") == []
+    texts = ["How can the net", " amount of entropy of", " the universe be massively decreased?", ""]
+    for nt in (1, 3, 8):
+        assert hutoken.batch_encode(texts, nt) == orc.batch_encode(texts, nt)
+    assert hutoken.batch_encode(texts, 0) == [[], [], [], []]
+    with pytest.raises(RuntimeError, match="hutoken: Error encoding texts"):
+        hutoken.batch_encode("not a list")
+    with pytest.raises(RuntimeError, match="embedded null character"):
+        hutoken.encode("a\0b")
+    assert hutoken.batch_encode(["ab\0cd"]) == [orc.encode("ab")]
