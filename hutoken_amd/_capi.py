@@ -18,7 +18,7 @@ EXPORTS = [
     "hutk_ctx_create", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
-    "hutk_set_timing",
+    "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read",
 ]
 
 _lib = None
@@ -66,6 +66,10 @@ def load(build_if_missing=True):
     L.hutk_set_timing.argtypes = [vp, i32]
     L.hutk_table_stats.restype = i32
     L.hutk_table_stats.argtypes = [vp, vp]
+    L.hutk_debug_profile.restype = i32
+    L.hutk_debug_profile.argtypes = [vp, i32]
+    L.hutk_debug_profile_read.restype = i32
+    L.hutk_debug_profile_read.argtypes = [vp, i64, vp]
     _lib = L
     return L
 
@@ -163,6 +167,15 @@ class Context:
         rc = load().hutk_encode_batch_device(self._h, d_bytes, d_offsets, n_docs, n_bytes, d_ids, ids_cap,
                                              d_out_offsets, d_status or None, d_err or None, stream or None)
         raise_for(rc)
+
+    def profile(self, enable):
+        load().hutk_debug_profile(self._h, 1 if enable else 0)
+
+    def profile_read(self, n_tiles):
+        import numpy as np
+        out = np.zeros(10, dtype=np.float64)
+        raise_for(load().hutk_debug_profile_read(self._h, n_tiles, out.ctypes.data))
+        return out.tolist()
 
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)

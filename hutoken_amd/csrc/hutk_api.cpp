@@ -65,6 +65,10 @@ struct hutk_ctx {
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
     DevBuf<uint32_t> d_item_sym, d_prefix_syms;
     DevBuf<uint8_t> d_item_direct;
+    DevBuf<uint16_t> d_bytepair16;
+    DevBuf<uint32_t> d_bytepair32;
+    DevBuf<long long> w_prof;
+    bool profile = false;
     DevTables dt{};
 
     // workspace
@@ -98,6 +102,8 @@ int upload_tables(hutk_ctx* c) {
     UP(c->d_char, T.char_slots);
     UP(c->d_sym_id, T.sym_id);
     UP(c->d_prefix_syms, T.prefix_syms);
+    UP(c->d_bytepair16, T.bytepair16);
+    UP(c->d_bytepair32, T.bytepair32);
 #undef UP
     HIP_TRY(c->d_item_sym.reserve(256));
     HIP_TRY(hipMemcpy(c->d_item_sym.p, T.item_sym, sizeof T.item_sym, hipMemcpyHostToDevice));
@@ -125,6 +131,8 @@ int upload_tables(hutk_ctx* c) {
     D.has_prefix = T.has_prefix;
     D.rank_is_sym = T.rank_is_sym;
     D.ident_ids = T.ident_ids;
+    D.sym16 = T.sym16;
+    D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
@@ -186,6 +194,11 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.counters = c->w_counters.p;
     W.cap_exc = cap_exc;
     W.pad_per_doc = (int32_t)pad;
+    W.prof = nullptr;
+    if (c->profile) {
+        HIP_TRY(c->w_prof.reserve((size_t)n_tiles * 10 + 16));
+        W.prof = c->w_prof.p;
+    }
     return HUTK_OK;
 }
 
@@ -195,6 +208,7 @@ void destroy(hutk_ctx* c) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_item_direct.release();
+        c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_err.release();
@@ -295,6 +309,26 @@ int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8) {
     out8[5] = T.rank_is_sym;
     out8[6] = T.ident_ids;
     out8[7] = (int64_t)T.prefix_syms.size();
+    return HUTK_OK;
+}
+
+// Diagnostic: per-phase clock64 stamps of k_tiles.  enable, run one batch, then read
+// the mean cycles between consecutive stamps over the first n_tiles tiles.
+int hutk_debug_profile(hutk_ctx* c, int enable) {
+    if (!c) return HUTK_E_ARG;
+    c->profile = enable != 0;
+    return HUTK_OK;
+}
+int hutk_debug_profile_read(hutk_ctx* c, int64_t n_tiles, double* out10) {
+    if (!c || !out10 || !c->w_prof.p || n_tiles <= 0) return set_err(HUTK_E_ARG, "no profile");
+    std::vector<long long> h((size_t)n_tiles * 10);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h.data(), c->w_prof.p, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 10; k++) out10[k] = 0;
+    for (int64_t t = 0; t < n_tiles; t++)
+        for (int k = 1; k < 10; k++) out10[k] += (double)(h[t * 10 + k] - h[t * 10 + k - 1]);
+    for (int k = 1; k < 10; k++) out10[k] /= (double)n_tiles;
+    for (int k = 1; k < 10; k++) out10[0] += out10[k];
     return HUTK_OK;
 }
 

@@ -38,6 +38,10 @@ struct DevTables {
     const int32_t* prefix_alone_ids;
     int32_t n_prefix_alone;
     int32_t is_byte_encoder, has_prefix, rank_is_sym, ident_ids;
+    // byte-encoder mode: merged symbol of the initial pair (byte b1, byte b2) at
+    // [b1 << 8 | b2], stored as uint16 when sym16 else uint32 (SYM_NONE when unranked)
+    const void* bytepair;
+    int32_t sym16;  // every symbol < 0xFFF0: LDS arrays hold 16-bit symbols
 };
 
 // one word the tile kernel hands to the exception kernel
@@ -68,6 +72,7 @@ struct Workspace {
     uint32_t* counters;        // [0] exception total, [1] exception work cursor
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
+    long long* prof;           // diagnostic: [n_tiles][10] clock64 stamps of k_tiles, or null
 };
 
 struct BatchArgs {

@@ -70,6 +70,12 @@ struct Tables {
     uint32_t char_mask = 0;
     uint32_t char_shift = 0;
 
+    // byte-encoder mode: merged symbol of the initial pair (byte b1, byte b2) at
+    // [b1 << 8 | b2]; the 16-bit form is used when every symbol is < 0xFFF0
+    bool sym16 = false;
+    std::vector<uint32_t> bytepair32;
+    std::vector<uint16_t> bytepair16;
+
     bool is_byte_encoder = false;
     bool has_prefix = false;
     std::vector<uint32_t> prefix_syms;        // units of the prefix when it is prepended to a word

@@ -156,48 +156,95 @@ __device__ __forceinline__ bool word_starts(const uint8_t* scode, const uint32_t
 }
 
 // ------------------------------------------------------------------------
+// symbol storage in LDS: 16-bit when the vocabulary has fewer than 65520 symbols
+// (halves the LDS footprint of the tile kernel -> more resident wavefronts)
+// ------------------------------------------------------------------------
+template <typename SymT> struct Sym;
+template <> struct Sym<uint32_t> {
+    static __device__ __forceinline__ uint32_t narrow(uint32_t v) { return v; }
+    static __device__ __forceinline__ uint32_t widen(uint32_t v) { return v; }
+    static constexpr uint32_t NONE = SYM_NONE;
+};
+template <> struct Sym<uint16_t> {
+    // SYM_NONE -> 0xFFFF, SYM_UNK -> 0xFFFE
+    static __device__ __forceinline__ uint16_t narrow(uint32_t v) {
+        return v == SYM_NONE ? (uint16_t)0xFFFFu : v == SYM_UNK ? (uint16_t)0xFFFEu : (uint16_t)v;
+    }
+    static __device__ __forceinline__ uint32_t widen(uint16_t v) {
+        return v == 0xFFFFu ? SYM_NONE : v == 0xFFFEu ? SYM_UNK : (uint32_t)v;
+    }
+    static constexpr uint16_t NONE = 0xFFFFu;
+};
+
+// two independent lookups: both first probes are issued before either is examined,
+// so their latencies overlap (the left and right neighbour of a fresh merge)
+__device__ __forceinline__ uint32_t pair_resolve(const DevTables& T, uint64_t s, uint64_t key, uint32_t h) {
+    for (;;) {
+        if ((s >> 20) == key) return (uint32_t)s & 0xFFFFFu;
+        if (s == SLOT_EMPTY) return SYM_NONE;
+        h = (h + 1) & T.pair_mask;
+        s = T.pair_slots[h];
+    }
+}
+__device__ __forceinline__ void pair_lookup2(const DevTables& T, bool on1, uint32_t l1, uint32_t r1, bool on2,
+                                             uint32_t l2, uint32_t r2, uint32_t& m1, uint32_t& m2) {
+    const uint32_t h1 = pair_hash(l1, r1) >> T.pair_shift;
+    const uint32_t h2 = pair_hash(l2, r2) >> T.pair_shift;
+    const uint64_t s1 = on1 ? T.pair_slots[h1] : SLOT_EMPTY;
+    const uint64_t s2 = on2 ? T.pair_slots[h2] : SLOT_EMPTY;
+    m1 = on1 ? pair_resolve(T, s1, ((uint64_t)l1 << 20) | r1, h1) : SYM_NONE;
+    m2 = on2 ? pair_resolve(T, s2, ((uint64_t)l2 << 20) | r2, h2) : SYM_NONE;
+}
+
+// 64 bits of a bitmap starting at bit `start` (the bitmap has 2 words of slack)
+__device__ __forceinline__ uint64_t bits64(const uint32_t* m, int start) {
+    const int k = start >> 5, sh = start & 31;
+    uint64_t v = ((uint64_t)m[k] | ((uint64_t)m[k + 1] << 32)) >> sh;
+    if (sh) v |= (uint64_t)m[k + 2] << (64 - sh);
+    return v;
+}
+
+// ------------------------------------------------------------------------
 // merge loop, one lane per word, arrays in LDS (src/core.c:66-209)
 //   Sw[0..n): symbols;  Mw[i]: merged symbol of (live unit i, next live unit)
+//   cand: bit i set <=> Mw[i] holds a rank (initial pairs are ranked before the call)
 // returns the number of surviving symbols, compacted to Sw[0..cnt)
 // ------------------------------------------------------------------------
-__device__ int bpe_lane(const DevTables& T, uint32_t* Sw, uint32_t* Mw, int n) {
+template <typename SymT>
+__device__ int bpe_lane(const DevTables& T, SymT* Sw, SymT* Mw, int n, uint64_t cand) {
     if (n <= 1) return n;
     uint64_t live = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    uint64_t cand = 0;
-    for (int i = 0; i + 1 < n; i++) {
-        const uint32_t m = pair_lookup(T, Sw[i], Sw[i + 1]);
-        Mw[i] = m;
-        if (m != SYM_NONE) cand |= 1ull << i;
-    }
     while (cand) {
         uint32_t best = 0xFFFFFFFFu;
         int p = 0;
         for (uint64_t c = cand; c; c &= c - 1) {
             const int i = __builtin_ctzll(c);
-            const uint32_t r = rank_of(T, Mw[i]);
+            const uint32_t r = rank_of(T, Sym<SymT>::widen(Mw[i]));
             if (r < best) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
                 best = r;
                 p = i;
             }
         }
         const int q = p + 1 + __builtin_ctzll(live >> (p + 1));
-        const uint32_t merged = Mw[p];
-        Sw[p] = merged;
+        const SymT merged_n = Mw[p];
+        const uint32_t merged = Sym<SymT>::widen(merged_n);
+        Sw[p] = merged_n;
         live &= ~(1ull << q);
         cand &= ~((1ull << q) | (1ull << p));
         const uint64_t right = (q >= 63) ? 0ull : (live >> (q + 1));
-        if (right) {
-            const int q2 = q + 1 + __builtin_ctzll(right);
-            const uint32_t m = pair_lookup(T, merged, Sw[q2]);
-            Mw[p] = m;
-            if (m != SYM_NONE) cand |= 1ull << p;
-        }
         const uint64_t left = live & ((1ull << p) - 1ull);
+        const int q2 = right ? q + 1 + __builtin_ctzll(right) : 0;
+        const int p0 = left ? 63 - __builtin_clzll(left) : 0;
+        uint32_t mr, ml;
+        pair_lookup2(T, right != 0, merged, right ? Sym<SymT>::widen(Sw[q2]) : 0u, left != 0,
+                     left ? Sym<SymT>::widen(Sw[p0]) : 0u, merged, mr, ml);
+        if (right) {
+            Mw[p] = Sym<SymT>::narrow(mr);
+            if (mr != SYM_NONE) cand |= 1ull << p;
+        }
         if (left) {
-            const int p0 = 63 - __builtin_clzll(left);
-            const uint32_t m = pair_lookup(T, Sw[p0], merged);
-            Mw[p0] = m;
-            if (m != SYM_NONE) cand |= 1ull << p0;
+            Mw[p0] = Sym<SymT>::narrow(ml);
+            if (ml != SYM_NONE) cand |= 1ull << p0;
             else cand &= ~(1ull << p0);
         }
     }
@@ -224,29 +271,40 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // ------------------------------------------------------------------------
 // k_tiles
 // ------------------------------------------------------------------------
-constexpr int WM_WORDS = (TILE_BYTES + HALO) / 32;  // 72 words of word-start bits
+constexpr int WM_WORDS = (TILE_BYTES + HALO) / 32;  // 72 words of per-position bits
 constexpr uint32_t EXC_FLAG = 0x8000u;
+constexpr int N_PHASE = 10;
 
+#define HUTK_STAMP(k)                                                          \
+    do {                                                                       \
+        if (W.prof && tid == 0) W.prof[tile * N_PHASE + (k)] = clock64();      \
+    } while (0)
+
+template <typename SymT, bool BYTE_MODE>
 __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
     __shared__ uint8_t scode[WINDOW];
     __shared__ uint32_t docm[WINDOW / 32 + 1];
-    __shared__ uint32_t wmask[WM_WORDS];
+    __shared__ uint32_t wmask[WM_WORDS + 2];   // word starts
+    __shared__ uint32_t rmask[WM_WORDS + 2];   // position r: pair (r, r+1) has a rank
     __shared__ uint32_t wpref[WM_WORDS + 1];
     __shared__ uint16_t wstart[TILE_BYTES + 2];
-    __shared__ uint16_t wcnt[TILE_BYTES];   // ids of word w; EXC_FLAG marks an exception word
-    __shared__ uint32_t wpos[TILE_BYTES + 1];  // low 16: ids before word w, high 16: exceptions before w
-    __shared__ uint32_t S[TILE_BYTES + HALO];
-    __shared__ uint32_t M[TILE_BYTES + HALO];
-    __shared__ uint32_t s_item_sym[256];
+    __shared__ uint16_t wcnt[TILE_BYTES];    // unit count, then id count; EXC_FLAG marks an exception word
+    __shared__ uint16_t wpos[TILE_BYTES + 1];  // ids before word w
+    __shared__ uint16_t order[TILE_BYTES];   // lane words, longest first
+    __shared__ SymT S[TILE_BYTES + HALO];
+    __shared__ SymT M[TILE_BYTES + HALO];
+    __shared__ SymT s_item_sym[256];
     __shared__ uint8_t s_item_direct[256];
     __shared__ uint32_t s_scan[TILE_THREADS];
+    __shared__ uint32_t hist[64], hbase[64];
     __shared__ uint32_t s_misc[4];
 
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
+    HUTK_STAMP(0);
 
     // ---- 1. stage bytes, tables -------------------------------------------------
     for (int c = tid; c < WINDOW / 16; c += TILE_THREADS) {
@@ -260,9 +318,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
         }
     }
-    s_item_sym[tid] = T.item_sym[tid];
+    s_item_sym[tid] = Sym<SymT>::narrow(T.item_sym[tid]);
     s_item_direct[tid] = T.item_direct[tid];
     if (tid < WINDOW / 32 + 1) docm[tid] = 0;
+    if (tid < 64) hist[tid] = 0;
+    if (tid < 2) { wmask[WM_WORDS + tid] = 0xFFFFFFFFu; rmask[WM_WORDS + tid] = 0; }
     for (int i = tid; i < TILE_BYTES + 2; i += TILE_THREADS) wstart[i] = 0xFFFFu;
     __syncthreads();
 
@@ -275,6 +335,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (li >= 0) atomicOr(&docm[li >> 5], 1u << (li & 31));
     }
     __syncthreads();
+    HUTK_STAMP(1);
 
     // ---- 3. character codes -----------------------------------------------------
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
@@ -286,6 +347,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (p >= t0 && p < tile_end && sb[li] == 0) raise(A.err, HUTK_E_NUL_BYTE);
     }
     __syncthreads();
+    HUTK_STAMP(2);
 
     // ---- 4. word-start flags -> bitmap --------------------------------------
     for (int r0 = 0; r0 < TILE_BYTES + HALO; r0 += TILE_THREADS) {
@@ -298,12 +360,31 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         }
     }
     __syncthreads();
+    HUTK_STAMP(3);
 
-    // ---- 5. word list -------------------------------------------------------------
+    // ---- 5. word list; byte mode: symbols and initial pair ranks per POSITION ---
     if (tid <= WM_WORDS) {
         uint32_t acc = 0;
         for (int k = 0; k < tid; k++) acc += __popc(wmask[k]);
         wpref[tid] = acc;
+    }
+    if (BYTE_MODE) {
+        // every adjacent byte pair of the window at once: no per-word loop, no divergence,
+        // one direct-indexed load each (the 65536-entry byte-pair table is L1/L2 resident)
+        const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
+        for (int r0 = 0; r0 < TILE_BYTES + HALO; r0 += TILE_THREADS) {
+            const int r = r0 + tid;
+            const uint32_t b = sb[r + LOOKBACK], b2 = sb[r + LOOKBACK + 1];
+            S[r] = s_item_sym[b];
+            SymT m = Sym<SymT>::NONE;
+            if (!((wmask[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u)) m = bp[(b << 8) | b2];
+            M[r] = m;
+            const unsigned long long bal = __ballot(m != Sym<SymT>::NONE);
+            if ((tid & 63) == 0) {
+                rmask[r >> 5] = (uint32_t)bal;
+                rmask[(r >> 5) + 1] = (uint32_t)(bal >> 32);
+            }
+        }
     }
     __syncthreads();
     const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
@@ -315,8 +396,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             wstart[idx++] = (uint16_t)(tid * 32 + __builtin_ctz(m));
     }
     __syncthreads();
+    HUTK_STAMP(4);
 
-    // ---- 6. one lane per word ------------------------------------------------
+    // ---- 6a. classify words, count units, histogram of unit counts -------------
     for (int w = tid; w < nW; w += TILE_THREADS) {
         const int ws = wstart[w];
         const int we = wstart[w + 1];
@@ -326,11 +408,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         int n = 0;
         if (!exc) {
             const int nb = we - ws;
-            if (T.is_byte_encoder) {
+            if (BYTE_MODE) {
                 n = nb;
-                if (n > LANE_MAX_UNITS) exc = true;
-                else
-                    for (int i = 0; i < nb; i++) S[ws + i] = s_item_sym[sb[lw + i]];
             } else {
                 int i = 0;
                 while (i < nb) {
@@ -341,7 +420,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                         else L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : 2;
                     }
                     uint32_t sym;
-                    if (s_item_direct[b]) sym = s_item_sym[b];
+                    if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
                     else if (L == 1) sym = SYM_UNK;
                     else {
                         uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
@@ -349,17 +428,58 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                         if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
                         sym = char_lookup(T, packed);
                     }
-                    if (n < LANE_MAX_UNITS) S[ws + n] = sym;
+                    if (n < LANE_MAX_UNITS) S[ws + n] = Sym<SymT>::narrow(sym);
                     n++;
                     i += L;
                 }
-                if (n > LANE_MAX_UNITS) exc = true;
             }
+            if (n > LANE_MAX_UNITS) exc = true;
         }
-        if (exc) wcnt[w] = (uint16_t)EXC_FLAG;
-        else wcnt[w] = (uint16_t)bpe_lane(T, S + ws, M + ws, n);
+        if (exc) {
+            wcnt[w] = (uint16_t)EXC_FLAG;
+        } else {
+            wcnt[w] = (uint16_t)n;
+            atomicAdd(&hist[n], 1u);
+        }
     }
     __syncthreads();
+    if (tid < 64) {  // longest first: bucket n starts after all longer buckets
+        uint32_t acc = 0;
+        for (int m = 63; m > tid; m--) acc += hist[m];
+        hbase[tid] = acc;
+        if (tid == 0) s_misc[1] = acc + hist[0];
+    }
+    __syncthreads();
+    const int nL = (int)s_misc[1];
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int w = tid; w < nW; w += TILE_THREADS) {
+        const uint32_t c = wcnt[w];
+        if (!(c & EXC_FLAG)) order[hbase[c] + atomicAdd(&hist[c], 1u)] = (uint16_t)w;
+    }
+    __syncthreads();
+    HUTK_STAMP(5);
+
+    // ---- 6b. one lane per word, longest words first -----------------------------
+    for (int k = tid; k < nL; k += TILE_THREADS) {
+        const int w = order[k];
+        const int ws = wstart[w];
+        const int n = wcnt[w];
+        uint64_t cand;
+        if (BYTE_MODE) {
+            cand = (n > 1) ? (bits64(rmask, ws) & ((1ull << (n - 1)) - 1ull)) : 0ull;
+        } else {
+            cand = 0;
+            for (int i = 0; i + 1 < n; i++) {
+                const uint32_t m = pair_lookup(T, Sym<SymT>::widen(S[ws + i]), Sym<SymT>::widen(S[ws + i + 1]));
+                M[ws + i] = Sym<SymT>::narrow(m);
+                if (m != SYM_NONE) cand |= 1ull << i;
+            }
+        }
+        wcnt[w] = (uint16_t)bpe_lane<SymT>(T, S + ws, M + ws, n, cand);
+    }
+    __syncthreads();
+    HUTK_STAMP(6);
 
     // ---- 7. scan of id counts (low half) and exception counts (high half) ---
     const int chunk = (nW + TILE_THREADS - 1) / TILE_THREADS;
@@ -381,16 +501,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     {
         uint32_t run = s_scan[tid] - mine;  // exclusive
         for (int w = wa; w < wb; w++) {
-            wpos[w] = run;
+            wpos[w] = (uint16_t)run;
             const uint32_t c = wcnt[w];
             run += (c & EXC_FLAG) ? 0x10000u : c;
         }
-        if (tid == TILE_THREADS - 1) wpos[nW] = s_scan[TILE_THREADS - 1];
     }
-    __syncthreads();
-    const uint32_t total = wpos[nW];
+    const uint32_t total = s_scan[TILE_THREADS - 1];
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
     if (tid == 0) {
+        wpos[nW] = (uint16_t)n_dense;
         uint32_t first = 0;
         if (n_exc) first = atomicAdd(&W.counters[0], n_exc);
         s_misc[0] = first;
@@ -401,33 +520,41 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         W.tile_nexc[tile] = n_exc;
     }
     __syncthreads();
+    HUTK_STAMP(7);
 
     // ---- 8. dense run + exception records -----------------------------------
-    const uint32_t exc_first = s_misc[0];
     int32_t* run_out = W.run + t0 + (nW ? wstart[0] : 0);
     for (int w = tid; w < nW; w += TILE_THREADS) {
         const uint32_t c = wcnt[w];
-        const uint32_t pos = wpos[w] & 0xFFFFu;
+        const uint32_t pos = wpos[w];
         const int ws = wstart[w];
-        if (c & EXC_FLAG) {
-            const uint64_t slot = (uint64_t)exc_first + (wpos[w] >> 16);
-            if ((int64_t)slot < W.cap_exc) {
-                ExcRec rec;
-                rec.ws = t0 + ws;
-                const int we = wstart[w + 1];
-                rec.len = (we == 0xFFFF) ? -1 : (we - ws);
-                rec.wpos = pos;
-                rec.cnt = 0;
-                rec.tile = (uint32_t)tile;
-                rec.tok_base = 0;
-                W.exc[slot] = rec;
-            } else {
-                raise(A.err, HUTK_E_MEMORY);
-            }
-        } else {
-            for (uint32_t j = 0; j < c; j++) run_out[pos + j] = sym_to_id(T, S[ws + j]);
+        if (!(c & EXC_FLAG)) {
+            for (uint32_t j = 0; j < c; j++) run_out[pos + j] = sym_to_id(T, Sym<SymT>::widen(S[ws + j]));
         }
     }
+    if (n_exc) {  // rare: records in word order (one thread walks the tile's words)
+        if (tid == 0) {
+            uint64_t slot = s_misc[0];
+            for (int w = 0; w < nW; w++) {
+                if (!(wcnt[w] & EXC_FLAG)) continue;
+                if ((int64_t)slot < W.cap_exc) {
+                    ExcRec rec;
+                    const int ws = wstart[w], we = wstart[w + 1];
+                    rec.ws = t0 + ws;
+                    rec.tok_base = 0;
+                    rec.len = (we == 0xFFFF) ? -1 : (we - ws);
+                    rec.wpos = wpos[w];
+                    rec.cnt = 0;
+                    rec.tile = (uint32_t)tile;
+                    W.exc[slot] = rec;
+                } else {
+                    raise(A.err, HUTK_E_MEMORY);
+                }
+                slot++;
+            }
+        }
+    }
+    HUTK_STAMP(8);
 
     // ---- 9. ids emitted before each document that starts in this tile ----------
     for (int64_t d = dfirst + tid; d <= A.n_docs; d += TILE_THREADS) {
@@ -436,8 +563,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (o < t0) continue;
         const int r = (int)(o - t0);
         const uint32_t widx = wpref[r >> 5] + __popc(wmask[r >> 5] & ((1u << (r & 31)) - 1u));
-        W.doc_tile_pos[d] = wpos[widx] & 0xFFFFu;
+        W.doc_tile_pos[d] = wpos[widx];
     }
+    HUTK_STAMP(9);
 }
 
 // ------------------------------------------------------------------------
@@ -800,7 +928,14 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_pre, dim3(g), dim3(256), 0, s, a, w);
 }
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_tiles, dim3((unsigned)a.n_tiles), dim3(TILE_THREADS), 0, s, t, a, w);
+    const dim3 g((unsigned)a.n_tiles), b(TILE_THREADS);
+    if (t.sym16) {
+        if (t.is_byte_encoder) hipLaunchKernelGGL((k_tiles<uint16_t, true>), g, b, 0, s, t, a, w);
+        else hipLaunchKernelGGL((k_tiles<uint16_t, false>), g, b, 0, s, t, a, w);
+    } else {
+        if (t.is_byte_encoder) hipLaunchKernelGGL((k_tiles<uint32_t, true>), g, b, 0, s, t, a, w);
+        else hipLaunchKernelGGL((k_tiles<uint32_t, false>), g, b, 0, s, t, a, w);
+    }
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     // fixed grid; every wavefront pulls records until the device counter runs out

@@ -348,6 +348,28 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
         }
     }
 
+    // ---- byte-encoder mode: direct table for the initial (byte, byte) pairs ----
+    T.sym16 = T.n_sym < 0xFFF0u;
+    if (is_byte_encoder) {
+        auto host_lookup = [&](uint32_t l, uint32_t r) -> uint32_t {
+            const uint64_t key = ((uint64_t)l << 20) | r;
+            uint32_t h = pair_hash(l, r) >> T.pair_shift;
+            for (;;) {
+                const uint64_t sl = T.pair_slots[h];
+                if ((sl >> 20) == key) return (uint32_t)sl & 0xFFFFFu;
+                if (sl == SLOT_EMPTY) return SYM_NONE;
+                h = (h + 1) & T.pair_mask;
+            }
+        };
+        if (T.sym16) T.bytepair16.assign(65536, 0xFFFFu); else T.bytepair32.assign(65536, SYM_NONE);
+        for (int b1 = 1; b1 < 256; b1++)
+            for (int b2 = 1; b2 < 256; b2++) {
+                const uint32_t m = host_lookup(T.item_sym[b1], T.item_sym[b2]);
+                if (m == SYM_NONE) continue;
+                if (T.sym16) T.bytepair16[(b1 << 8) | b2] = (uint16_t)m; else T.bytepair32[(b1 << 8) | b2] = m;
+            }
+    }
+
     // ---- non-byte mode: multi-byte character -> symbol ----
     if (!is_byte_encoder) {
         std::vector<std::pair<uint32_t, uint32_t>> chars;

@@ -115,6 +115,13 @@ int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8);
  * ("encode tiles") and the whole enqueue.  Synchronises on those events. */
 int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
 
+/* Diagnostic build aid: clock64 stamps at the phase boundaries of the tile kernel.
+ * hutk_debug_profile(ctx, 1), run a batch, then hutk_debug_profile_read returns the
+ * mean shader cycles per phase over the first n_tiles tiles (out10[0] = their sum,
+ * out10[k] = phase k).  Never enabled in timed runs. */
+int hutk_debug_profile(hutk_ctx* ctx, int enable);
+int hutk_debug_profile_read(hutk_ctx* ctx, int64_t n_tiles, double* out10);
+
 /* Per-call profiling events cost a little; they are on by default. */
 void hutk_set_timing(hutk_ctx* ctx, int enabled);
 

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Diagnostic: mean shader cycles per phase of k_tiles (clock64 stamps), GPU only."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hutoken_amd import _capi, data, synth
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+n_docs = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+vocab = sys.argv[3] if len(sys.argv) > 3 else "VG"
+vp, sp, kw = data.vocab_files(vocab)
+ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+d, o = synth.corpus(name, n_docs)
+dev = torch.device("cuda", 0)
+db, do = torch.from_numpy(d).to(dev), torch.from_numpy(o).to(dev)
+cap = ctx.ids_capacity(len(d), n_docs)
+ids = torch.empty(cap, dtype=torch.int32, device=dev)
+oo = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+err = torch.zeros(1, dtype=torch.int32, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+def run():
+    ctx.encode_device(db.data_ptr(), do.data_ptr(), n_docs, len(d), ids.data_ptr(), cap, oo.data_ptr(), 0, err.data_ptr(), st)
+for _ in range(3): run()
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5): run()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 5
+print(f"{name} {n_docs} docs {len(d)/1e6:.1f} MB vocab {vocab}: {dt*1e3:.3f} ms/step  {len(d)/dt/1e9:.2f} GB/s  tile-kernel {ctx.last_timing()[0]:.3f} ms  ids {int(oo[-1])}")
+ctx.profile(True)
+run(); torch.cuda.synchronize()
+n_tiles = (len(d) + 2047) // 2048
+ph = ctx.profile_read(n_tiles)
+names = ["total", "1 stage+docs", "2 codes", "3 flags", "4 wordlist+pairs", "5 classify+sort", "6 merge", "7 scan", "8 write", "9 docpos"]
+for nme, v in zip(names, ph):
+    print(f"  {nme:18s} {v:10.0f} cyc  {100*v/ph[0]:5.1f}%")
+ctx.profile(False)
