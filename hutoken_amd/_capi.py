@@ -18,7 +18,7 @@ EXPORTS = [
     "hutk_ctx_create", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
-    "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read",
+    "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
 ]
 
 _lib = None
@@ -68,6 +68,8 @@ def load(build_if_missing=True):
     L.hutk_table_stats.argtypes = [vp, vp]
     L.hutk_debug_profile.restype = i32
     L.hutk_debug_profile.argtypes = [vp, i32]
+    L.hutk_debug_tile_bytes.restype = i32
+    L.hutk_debug_tile_bytes.argtypes = []
     L.hutk_debug_profile_read.restype = i32
     L.hutk_debug_profile_read.argtypes = [vp, i64, vp]
     _lib = L

@@ -319,6 +319,7 @@ int hutk_debug_profile(hutk_ctx* c, int enable) {
     c->profile = enable != 0;
     return HUTK_OK;
 }
+int hutk_debug_tile_bytes(void) { return TILE_BYTES; }
 int hutk_debug_profile_read(hutk_ctx* c, int64_t n_tiles, double* out10) {
     if (!c || !out10 || !c->w_prof.p || n_tiles <= 0) return set_err(HUTK_E_ARG, "no profile");
     std::vector<long long> h((size_t)n_tiles * 10);

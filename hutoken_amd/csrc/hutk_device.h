@@ -10,14 +10,14 @@
 namespace hutk {
 
 // ---- geometry of the tile kernel -----------------------------------------
-constexpr int TILE_BYTES = 2048;   // input bytes owned by one workgroup
-constexpr int TILE_THREADS = 256;  // 4 wavefronts
+constexpr int TILE_BYTES = 960;    // input bytes owned by one wavefront
+constexpr int TILE_THREADS = 64;   // 1 wavefront: no inter-wave barriers in the hot kernel
 constexpr int LOOKBACK = 16;       // bytes staged before the tile (classification needs <= 8)
-constexpr int HALO = 256;          // bytes staged after the tile (a word may end there)
+constexpr int HALO = 64;           // positions classified after the tile (a word may end there)
 constexpr int TAIL = 16;           // look-ahead for the last halo positions
-constexpr int WINDOW = LOOKBACK + TILE_BYTES + HALO + TAIL;  // 2336 staged bytes
-constexpr int LANE_MAX_UNITS = 48;   // longest word a single lane merges
-constexpr int LANE_MAX_BYTES = 192;  // and its byte length (non-byte mode: up to 4 bytes/unit)
+constexpr int WINDOW = LOOKBACK + TILE_BYTES + HALO + TAIL;  // 1056 staged bytes
+constexpr int LANE_MAX_UNITS = 32;   // longest word a single lane merges (32-bit live/candidate masks)
+constexpr int LANE_MAX_BYTES = 63;   // and its byte length (its end must be within 63 positions)
 constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units merge in LDS
 
 // per-position codes produced by the classifier (parser.c:24-183 restated as a

@@ -4,21 +4,27 @@
 // Pipeline of one batch (all on one stream, no host round trip):
 //
 //   k_pre      per tile: first document that can touch the tile (binary search)
-//   k_tiles    THE hot kernel.  One 256-thread workgroup owns 2048 input bytes:
-//                1. coalesced 16-byte loads of the bytes (+16 before, +272 after) into LDS
+//   k_tiles    THE hot kernel.  ONE WAVEFRONT owns 960 input bytes (no workgroup barrier
+//              ever waits on another wavefront's long word):
+//                1. coalesced 16-byte loads of the bytes (+16 before, +80 after) into LDS
 //                2. document-start bitmap of the window
-//                3. per-byte character code from a +-3 byte neighbourhood
-//                   (the reference's splitter, src/parser.c:24-183, is locally decidable)
-//                4. word-start flags -> __ballot -> bitmap -> compact word list
-//                5. ONE LANE PER WORD: initial symbols (byte -> symbol LUT / character
-//                   hash), pair ranks from the device pair table, then the reference's
-//                   merge rule "leftmost pair of minimal rank" (src/core.c:66-209,
-//                   src/queue.c:152-199) with symbols and pair results held in LDS
-//                6. workgroup scan of per-word id counts, dense id run written out
-//                7. ids-before-document-start for every document that starts in the tile
-//              Words a lane cannot take (more than 48 units, end outside the staged
-//              window, or first word of a document when a prefix is configured) become
-//              exception records.
+//                3. each lane classifies its 16 positions IN REGISTERS from a 32-byte
+//                   window (the reference's splitter, src/parser.c:24-183, is a function
+//                   of a +-5 byte neighbourhood) and emits 16 word-start bits
+//                4. byte-encoder mode: symbols (byte -> symbol LUT) and the rank of every
+//                   adjacent byte pair straight from a 65536-entry table, 16 independent
+//                   loads per lane
+//                5. words bucketed by unit count, longest first
+//                6. PERSISTENT LANES, ONE WORD PER LANE: each lane pulls the next word
+//                   from an LDS cursor and all lanes take one step of the reference's
+//                   merge rule "leftmost pair of minimal rank" per trip (src/core.c:66-209,
+//                   src/queue.c:152-199); symbols and pair results live in LDS, the two
+//                   new neighbour pairs are looked up together in the device pair table
+//                7. wave scan (__shfl_up) of per-word id counts, dense id run written out
+//                8. ids-before-document-start for every document that starts in the tile
+//              Words a lane cannot take (more than 32 units or 63 bytes, end outside the
+//              staged window, or first word of a document when a prefix is configured)
+//              become exception records.
 //   k_exc      one wavefront per exception word, work pulled from a device counter:
 //              the same merge rule, cooperatively (parallel min over the pair array,
 //              __shfl_xor reduction), arrays in LDS up to 1024 units, else in HBM.
@@ -32,6 +38,7 @@
 // hutk_loader.cpp; with unique ids "smaller merged symbol" == "smaller rank".
 #include <hip/hip_runtime.h>
 
+#include "hutk_classify.h"
 #include "hutk_device.h"
 
 namespace hutk {
@@ -269,45 +276,62 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 }
 
 // ------------------------------------------------------------------------
-// k_tiles
+// k_tiles: ONE WAVEFRONT per tile of 960 input bytes (+64 bytes of halo in which a
+// word that starts in the tile may end).  Lane l owns positions 16l .. 16l+15.
+// No workgroup barriers: a long word delays only its own wavefront.
 // ------------------------------------------------------------------------
-constexpr int WM_WORDS = (TILE_BYTES + HALO) / 32;  // 72 words of per-position bits
-constexpr uint32_t EXC_FLAG = 0x8000u;
+constexpr uint32_t EXC_MARK = 0x8000u;  // M[word start] of an exception word
 constexpr int N_PHASE = 10;
+constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
+static_assert(NPOS == 64 * 16, "16 positions per lane");
 
 #define HUTK_STAMP(k)                                                          \
     do {                                                                       \
-        if (W.prof && tid == 0) W.prof[tile * N_PHASE + (k)] = clock64();      \
+        if (W.prof && lane == 0) W.prof[tile * N_PHASE + (k)] = clock64();     \
     } while (0)
+
+// byte k (0..31) of a 32-byte register window
+struct Win { uint64_t a, b, c, d; };
+__device__ __forceinline__ uint32_t win_byte(const Win w, int k) {
+    const uint64_t v = (k < 16) ? ((k < 8) ? w.a : w.b) : ((k < 24) ? w.c : w.d);
+    return (uint32_t)(v >> ((k & 7) * 8)) & 0xFFu;
+}
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
+    uint32_t inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    *total = __shfl(inc, 63, 64);
+    return inc - v;
+}
 
 template <typename SymT, bool BYTE_MODE>
 __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
-    __shared__ uint8_t scode[WINDOW];
-    __shared__ uint32_t docm[WINDOW / 32 + 1];
-    __shared__ uint32_t wmask[WM_WORDS + 2];   // word starts
-    __shared__ uint32_t rmask[WM_WORDS + 2];   // position r: pair (r, r+1) has a rank
-    __shared__ uint32_t wpref[WM_WORDS + 1];
-    __shared__ uint16_t wstart[TILE_BYTES + 2];
-    __shared__ uint16_t wcnt[TILE_BYTES];    // unit count, then id count; EXC_FLAG marks an exception word
-    __shared__ uint16_t wpos[TILE_BYTES + 1];  // ids before word w
-    __shared__ uint16_t order[TILE_BYTES];   // lane words, longest first
-    __shared__ SymT S[TILE_BYTES + HALO];
-    __shared__ SymT M[TILE_BYTES + HALO];
+    __shared__ uint32_t docm[WINDOW / 32 + 3];
+    __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
+    __shared__ __attribute__((aligned(8))) uint16_t rmask16[64 + 8];  // pair (r, r+1) has a rank
+    __shared__ uint32_t lanepref[64];                                  // ids before lane l's positions
+    __shared__ uint16_t order[TILE_BYTES];                              // lane words, longest first: ws | n << 10
+    __shared__ __attribute__((aligned(16))) SymT S[NPOS];
+    __shared__ __attribute__((aligned(16))) SymT M[NPOS];
     __shared__ SymT s_item_sym[256];
     __shared__ uint8_t s_item_direct[256];
-    __shared__ uint32_t s_scan[TILE_THREADS];
     __shared__ uint32_t hist[64], hbase[64];
-    __shared__ uint32_t s_misc[4];
+    __shared__ uint32_t s_next;
 
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
+    const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
+    const uint32_t* rmask32 = reinterpret_cast<const uint32_t*>(rmask16);
     HUTK_STAMP(0);
 
-    // ---- 1. stage bytes, tables -------------------------------------------------
-    for (int c = tid; c < WINDOW / 16; c += TILE_THREADS) {
+    // ---- 1. stage bytes and tables ------------------------------------------------
+    for (int c = lane; c < WINDOW / 16; c += 64) {
         const int64_t p = gw + 16 * c;
         if (p >= 0 && p + 16 <= A.n_bytes) {
             *reinterpret_cast<uint4*>(sb + 16 * c) = *reinterpret_cast<const uint4*>(A.bytes + p);
@@ -318,17 +342,18 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
         }
     }
-    s_item_sym[tid] = Sym<SymT>::narrow(T.item_sym[tid]);
-    s_item_direct[tid] = T.item_direct[tid];
-    if (tid < WINDOW / 32 + 1) docm[tid] = 0;
-    if (tid < 64) hist[tid] = 0;
-    if (tid < 2) { wmask[WM_WORDS + tid] = 0xFFFFFFFFu; rmask[WM_WORDS + tid] = 0; }
-    for (int i = tid; i < TILE_BYTES + 2; i += TILE_THREADS) wstart[i] = 0xFFFFu;
+    for (int i = lane; i < 256; i += 64) {
+        s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
+        s_item_direct[i] = T.item_direct[i];
+    }
+    if (lane < WINDOW / 32 + 3) docm[lane] = 0;
+    hist[lane] = 0;
+    if (lane < 8) { wmask16[64 + lane] = 0xFFFFu; rmask16[64 + lane] = 0; }
     __syncthreads();
 
     // ---- 2. document starts inside the window -------------------------------
     const int64_t dfirst = W.tile_first_doc[tile];
-    for (int64_t d = dfirst + tid; d <= A.n_docs; d += TILE_THREADS) {
+    for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
         const int64_t o = A.offsets[d];
         if (o >= gw + WINDOW) break;
         const int li = (int)(o - gw);
@@ -337,87 +362,89 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __syncthreads();
     HUTK_STAMP(1);
 
-    // ---- 3. character codes -----------------------------------------------------
-    const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
-    for (int li = tid; li < WINDOW; li += TILE_THREADS) {
-        uint8_t c = C_BAD;
-        if (li >= 4 && li < WINDOW - 4) c = code_at(sb, docm, li);
-        scode[li] = c;
-        const int64_t p = gw + li;
-        if (p >= t0 && p < tile_end && sb[li] == 0) raise(A.err, HUTK_E_NUL_BYTE);
+    // ---- 3. classification in registers: 32-byte window per lane ------------------
+    // window-local index k <-> window index kb - 8 + k; own positions are k = 8..23
+    const int kb = LOOKBACK + 16 * lane;
+    Win w;
+    {
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(sb + kb - 8);
+        w.a = src[0]; w.b = src[1]; w.c = src[2]; w.d = src[3];
     }
-    __syncthreads();
+    const uint32_t dbits = (uint32_t)bits64(docm, kb - 8);
+    const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
+    uint32_t flags;
+    {
+        const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
+                                (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
+        bool exotic;
+        flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
+        if (exotic) flags = classify16_exact(dw, dbits);  // overlong encodings: per-position decode
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int64_t p = t0 + 16 * lane + j;
+        if (p < tile_end && win_byte(w, 8 + j) == 0) raise(A.err, HUTK_E_NUL_BYTE);
+    }
+    wmask16[lane] = (uint16_t)flags;
     HUTK_STAMP(2);
 
-    // ---- 4. word-start flags -> bitmap --------------------------------------
-    for (int r0 = 0; r0 < TILE_BYTES + HALO; r0 += TILE_THREADS) {
-        const int r = r0 + tid;
-        const bool f = word_starts(scode, docm, r + LOOKBACK);
-        const unsigned long long bal = __ballot(f);
-        if ((tid & 63) == 0) {
-            wmask[r >> 5] = (uint32_t)bal;
-            wmask[(r >> 5) + 1] = (uint32_t)(bal >> 32);
+    // ---- 4. byte mode: symbols and initial pair ranks for all 16 positions at once ---
+    uint32_t rbits = 0;
+    if (BYTE_MODE) {
+        uint32_t nf = __shfl_down(flags, 1, 64) & 1u;
+        if (lane == 63) nf = 1u;
+        const uint32_t fl17 = flags | (nf << 16);
+        const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
+        SymT sv[16], mv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t b = win_byte(w, 8 + j), b2 = win_byte(w, 9 + j);
+            sv[j] = s_item_sym[b];
+            mv[j] = ((fl17 >> (j + 1)) & 1u) ? Sym<SymT>::NONE : bp[(b << 8) | b2];
         }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            S[16 * lane + j] = sv[j];
+            M[16 * lane + j] = mv[j];
+            rbits |= (uint32_t)(mv[j] != Sym<SymT>::NONE) << j;
+        }
+        rmask16[lane] = (uint16_t)rbits;
     }
     __syncthreads();
     HUTK_STAMP(3);
 
-    // ---- 5. word list; byte mode: symbols and initial pair ranks per POSITION ---
-    if (tid <= WM_WORDS) {
-        uint32_t acc = 0;
-        for (int k = 0; k < tid; k++) acc += __popc(wmask[k]);
-        wpref[tid] = acc;
-    }
-    if (BYTE_MODE) {
-        // every adjacent byte pair of the window at once: no per-word loop, no divergence,
-        // one direct-indexed load each (the 65536-entry byte-pair table is L1/L2 resident)
-        const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
-        for (int r0 = 0; r0 < TILE_BYTES + HALO; r0 += TILE_THREADS) {
-            const int r = r0 + tid;
-            const uint32_t b = sb[r + LOOKBACK], b2 = sb[r + LOOKBACK + 1];
-            S[r] = s_item_sym[b];
-            SymT m = Sym<SymT>::NONE;
-            if (!((wmask[(r + 1) >> 5] >> ((r + 1) & 31)) & 1u)) m = bp[(b << 8) | b2];
-            M[r] = m;
-            const unsigned long long bal = __ballot(m != Sym<SymT>::NONE);
-            if ((tid & 63) == 0) {
-                rmask[r >> 5] = (uint32_t)bal;
-                rmask[(r >> 5) + 1] = (uint32_t)(bal >> 32);
-            }
-        }
-    }
-    __syncthreads();
+    // ---- 5. words of this lane's positions: unit counts, histogram, order ---------
     const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
-    const int nW = (limit <= 0) ? 0
-                                : (int)(wpref[limit >> 5] + __popc(wmask[limit >> 5] & ((1u << (limit & 31)) - 1u)));
-    if (tid < WM_WORDS) {
-        uint32_t idx = wpref[tid];
-        for (uint32_t m = wmask[tid]; m && idx < TILE_BYTES + 2; m &= m - 1)
-            wstart[idx++] = (uint16_t)(tid * 32 + __builtin_ctz(m));
+    uint32_t own = flags;                    // starts that are words of this tile
+    {
+        const int lo = 16 * lane;
+        if (lo >= limit) own = 0;
+        else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
     }
-    __syncthreads();
-    HUTK_STAMP(4);
-
-    // ---- 6a. classify words, count units, histogram of unit counts -------------
-    for (int w = tid; w < nW; w += TILE_THREADS) {
-        const int ws = wstart[w];
-        const int we = wstart[w + 1];
-        const int lw = ws + LOOKBACK;
-        const bool docfirst = bit_at(docm, lw);
-        bool exc = (we == 0xFFFF) || (we - ws > LANE_MAX_BYTES) || (T.has_prefix && docfirst);
+    uint32_t excbits = 0;  // own starts that became exception words
+    for (uint32_t m = own; m; m &= m - 1) {
+        const int j = __builtin_ctz(m);
+        const int ws = 16 * lane + j;
+        // end of the word: the next start bit within 63 positions (bits beyond the
+        // window are ones, which is only true when the data ends there)
+        const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+        const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+        const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+        const bool docfirst = bit_at(docm, ws + LOOKBACK);
+        bool exc = !known_end || nb > LANE_MAX_BYTES || (T.has_prefix && docfirst);
         int n = 0;
         if (!exc) {
-            const int nb = we - ws;
             if (BYTE_MODE) {
                 n = nb;
             } else {
+                const int lw = ws + LOOKBACK;
                 int i = 0;
                 while (i < nb) {
                     const uint32_t b = sb[lw + i];
                     int L = 1;
                     if (b >= 0x80u) {
-                        if (scode[lw + i] == C_BAD) raise(A.err, HUTK_E_INVALID_UTF8);
-                        else L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : 2;
+                        L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                        if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
                     }
                     uint32_t sym;
                     if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
@@ -436,135 +463,234 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             if (n > LANE_MAX_UNITS) exc = true;
         }
         if (exc) {
-            wcnt[w] = (uint16_t)EXC_FLAG;
+            excbits |= 1u << j;
+            M[ws] = (SymT)EXC_MARK;
         } else {
-            wcnt[w] = (uint16_t)n;
             atomicAdd(&hist[n], 1u);
         }
     }
     __syncthreads();
-    if (tid < 64) {  // longest first: bucket n starts after all longer buckets
+    {  // longest first: bucket n starts after all longer buckets
         uint32_t acc = 0;
-        for (int m = 63; m > tid; m--) acc += hist[m];
-        hbase[tid] = acc;
-        if (tid == 0) s_misc[1] = acc + hist[0];
+        for (int m = 63; m > lane; m--) acc += hist[m];
+        hbase[lane] = acc;
     }
     __syncthreads();
-    const int nL = (int)s_misc[1];
-    if (tid < 64) hist[tid] = 0;
+    const int nL = (int)(hbase[0] + hist[0]);
     __syncthreads();
-    for (int w = tid; w < nW; w += TILE_THREADS) {
-        const uint32_t c = wcnt[w];
-        if (!(c & EXC_FLAG)) order[hbase[c] + atomicAdd(&hist[c], 1u)] = (uint16_t)w;
+    hist[lane] = 0;
+    if (lane == 0) s_next = 64;
+    __syncthreads();
+    for (uint32_t m = own & ~excbits; m; m &= m - 1) {
+        const int j = __builtin_ctz(m);
+        const int ws = 16 * lane + j;
+        const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
+        int n = nb;
+        if (!BYTE_MODE) {  // units = characters = lead bytes
+            n = 0;
+            for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
+        }
+        order[hbase[n] + atomicAdd(&hist[n], 1u)] = (uint16_t)(ws | (n << 10));
+    }
+    __syncthreads();
+    HUTK_STAMP(4);
+
+    // ---- 6. merge: persistent lanes pull words, one merge step per trip ------------
+    // Each lane keeps (br, bp, bm) = rank, position and merged symbol of its word's best pair.
+    // A step applies that merge, ISSUES the two pair-table loads for the new neighbour pairs,
+    // rescans the untouched candidates in LDS while those loads are in flight, and then
+    // picks the next best among {rescan, new left pair, new right pair}.
+    {
+        int k = lane;
+        bool have = false;
+        int ws = 0;
+        uint32_t live = 0, cand = 0;  // lane words have at most 32 units
+        uint32_t br = 0xFFFFFFFFu;
+        int bp = 0;
+        SymT bm = 0;
+        for (;;) {
+            // finish exhausted words and fetch until this lane holds a word with work
+            while ((have && cand == 0) || (!have && k < nL)) {
+                if (have) {
+                    int cnt = 0;
+                    for (uint32_t c = live; c; c &= c - 1) S[ws + cnt++] = S[ws + __builtin_ctz(c)];
+                    M[ws] = (SymT)cnt;
+                    have = false;
+                    k = (int)atomicAdd(&s_next, 1u);
+                }
+                if (k < nL) {
+                    const uint32_t e = order[k];
+                    ws = (int)(e & 1023u);
+                    const int n = (int)(e >> 10);
+                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                    if (BYTE_MODE) {
+                        cand = (uint32_t)bits64(rmask32, ws) & (live >> 1);
+                    } else {
+                        cand = 0;
+                        for (int i = 0; i + 1 < n; i++) {
+                            const uint32_t m =
+                                pair_lookup(T, Sym<SymT>::widen(S[ws + i]), Sym<SymT>::widen(S[ws + i + 1]));
+                            M[ws + i] = Sym<SymT>::narrow(m);
+                            if (m != SYM_NONE) cand |= 1u << i;
+                        }
+                    }
+                    br = 0xFFFFFFFFu;
+                    for (uint32_t c = cand; c; c &= c - 1) {
+                        const int i = __builtin_ctz(c);
+                        const SymT mv = M[ws + i];
+                        const uint32_t r = rank_of(T, Sym<SymT>::widen(mv));
+                        if (r < br) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
+                            br = r;
+                            bp = i;
+                            bm = mv;
+                        }
+                    }
+                    have = true;
+                }
+            }
+            if (!__any(have)) break;
+            if (have) {
+                SymT* Sw = S + ws;
+                SymT* Mw = M + ws;
+                const int p = bp;
+                const uint32_t merged = Sym<SymT>::widen(bm);
+                // q: next live unit after p (exists: bit p of cand was set)
+                const uint32_t above = live & ~((2u << p) - 1u);
+                const int q = __builtin_ctz(above);
+                Sw[p] = bm;
+                live &= ~(1u << q);
+                cand &= ~((1u << q) | (1u << p));
+                const uint32_t right = above & (above - 1u);    // live units after q
+                const uint32_t left = live & ((1u << p) - 1u);  // live units before p
+                const int q2 = right ? __builtin_ctz(right) : 0;
+                const int p0 = left ? 31 - __builtin_clz(left) : 0;
+                const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
+                const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
+                // issue both first probes
+                const uint32_t h1 = pair_hash(merged, sr) >> T.pair_shift;
+                const uint32_t h2 = pair_hash(sl, merged) >> T.pair_shift;
+                const uint64_t s1 = right ? T.pair_slots[h1] : SLOT_EMPTY;
+                const uint64_t s2 = left ? T.pair_slots[h2] : SLOT_EMPTY;
+                // rescan what the merge did not touch
+                if (left) cand &= ~(1u << p0);
+                br = 0xFFFFFFFFu;
+                for (uint32_t c = cand; c; c &= c - 1) {
+                    const int i = __builtin_ctz(c);
+                    const SymT mv = Mw[i];
+                    const uint32_t r = rank_of(T, Sym<SymT>::widen(mv));
+                    if (r < br) {
+                        br = r;
+                        bp = i;
+                        bm = mv;
+                    }
+                }
+                // the two new pairs
+                const uint32_t mr = right ? pair_resolve(T, s1, ((uint64_t)merged << 20) | sr, h1) : SYM_NONE;
+                const uint32_t ml = left ? pair_resolve(T, s2, ((uint64_t)sl << 20) | merged, h2) : SYM_NONE;
+                if (right) {
+                    const SymT mn = Sym<SymT>::narrow(mr);
+                    Mw[p] = mn;
+                    if (mr != SYM_NONE) {
+                        cand |= 1u << p;
+                        const uint32_t r = rank_of(T, mr);
+                        if (r < br || (r == br && p < bp)) {
+                            br = r;
+                            bp = p;
+                            bm = mn;
+                        }
+                    }
+                }
+                if (left) {
+                    const SymT mn = Sym<SymT>::narrow(ml);
+                    Mw[p0] = mn;
+                    if (ml != SYM_NONE) {
+                        cand |= 1u << p0;
+                        const uint32_t r = rank_of(T, ml);
+                        if (r < br || (r == br && p0 < bp)) {
+                            br = r;
+                            bp = p0;
+                            bm = mn;
+                        }
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
     HUTK_STAMP(5);
 
-    // ---- 6b. one lane per word, longest words first -----------------------------
-    for (int k = tid; k < nL; k += TILE_THREADS) {
-        const int w = order[k];
-        const int ws = wstart[w];
-        const int n = wcnt[w];
-        uint64_t cand;
-        if (BYTE_MODE) {
-            cand = (n > 1) ? (bits64(rmask, ws) & ((1ull << (n - 1)) - 1ull)) : 0ull;
-        } else {
-            cand = 0;
-            for (int i = 0; i + 1 < n; i++) {
-                const uint32_t m = pair_lookup(T, Sym<SymT>::widen(S[ws + i]), Sym<SymT>::widen(S[ws + i + 1]));
-                M[ws + i] = Sym<SymT>::narrow(m);
-                if (m != SYM_NONE) cand |= 1ull << i;
-            }
-        }
-        wcnt[w] = (uint16_t)bpe_lane<SymT>(T, S + ws, M + ws, n, cand);
+    // ---- 7. per-position epilogue: counts -> scan -> ids out, exception records ----
+    uint32_t mine = 0;  // low 16: ids, high 16: exception words
+    for (uint32_t m = own; m; m &= m - 1) {
+        const uint32_t c = M[16 * lane + __builtin_ctz(m)];
+        mine += (c == EXC_MARK) ? 0x10000u : c;
     }
-    __syncthreads();
-    HUTK_STAMP(6);
-
-    // ---- 7. scan of id counts (low half) and exception counts (high half) ---
-    const int chunk = (nW + TILE_THREADS - 1) / TILE_THREADS;
-    const int wa = tid * chunk < nW ? tid * chunk : nW;
-    const int wb = wa + chunk < nW ? wa + chunk : nW;
-    uint32_t mine = 0;
-    for (int w = wa; w < wb; w++) {
-        const uint32_t c = wcnt[w];
-        mine += (c & EXC_FLAG) ? 0x10000u : c;
-    }
-    s_scan[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < TILE_THREADS; off <<= 1) {
-        const uint32_t v = (tid >= off) ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += v;
-        __syncthreads();
-    }
-    {
-        uint32_t run = s_scan[tid] - mine;  // exclusive
-        for (int w = wa; w < wb; w++) {
-            wpos[w] = (uint16_t)run;
-            const uint32_t c = wcnt[w];
-            run += (c & EXC_FLAG) ? 0x10000u : c;
-        }
-    }
-    const uint32_t total = s_scan[TILE_THREADS - 1];
+    uint32_t total;
+    uint32_t run = wave_excl_scan(mine, lane, &total);
+    lanepref[lane] = run & 0xFFFFu;
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
-    if (tid == 0) {
-        wpos[nW] = (uint16_t)n_dense;
-        uint32_t first = 0;
-        if (n_exc) first = atomicAdd(&W.counters[0], n_exc);
-        s_misc[0] = first;
+    const unsigned long long has_words = __ballot(own != 0);
+    const int first_lane = has_words ? __builtin_ctzll(has_words) : 0;
+    const uint32_t first_flags = __shfl(own, first_lane, 64);
+    const uint32_t run_start = has_words ? (uint32_t)(16 * first_lane + __builtin_ctz(first_flags)) : 0u;
+    uint32_t exc_first = 0;
+    if (lane == 0) {
+        if (n_exc) exc_first = atomicAdd(&W.counters[0], n_exc);
         W.tile_count[tile] = n_dense;
         W.tile_dense[tile] = n_dense;
-        W.tile_run_start[tile] = nW ? wstart[0] : 0u;
-        W.tile_exc_first[tile] = first;
+        W.tile_run_start[tile] = run_start;
+        W.tile_exc_first[tile] = exc_first;
         W.tile_nexc[tile] = n_exc;
+    }
+    exc_first = __shfl(exc_first, 0, 64);
+    HUTK_STAMP(6);
+    int32_t* run_out = W.run + t0 + run_start;
+    for (uint32_t m = own; m; m &= m - 1) {
+        const int ws = 16 * lane + __builtin_ctz(m);
+        const uint32_t c = M[ws];
+        const uint32_t pos = run & 0xFFFFu;
+        if (c == EXC_MARK) {
+            const uint64_t slot = (uint64_t)exc_first + (run >> 16);
+            if ((int64_t)slot < W.cap_exc) {
+                const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+                const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                ExcRec rec;
+                rec.ws = t0 + ws;
+                rec.tok_base = 0;
+                rec.len = known_end ? nb : -1;
+                rec.wpos = pos;
+                rec.cnt = 0;
+                rec.tile = (uint32_t)tile;
+                W.exc[slot] = rec;
+            } else {
+                raise(A.err, HUTK_E_MEMORY);
+            }
+            run += 0x10000u;
+        } else {
+            for (uint32_t j = 0; j < c; j++) run_out[pos + j] = sym_to_id(T, Sym<SymT>::widen(S[ws + j]));
+            run += c;
+        }
     }
     __syncthreads();
     HUTK_STAMP(7);
 
-    // ---- 8. dense run + exception records -----------------------------------
-    int32_t* run_out = W.run + t0 + (nW ? wstart[0] : 0);
-    for (int w = tid; w < nW; w += TILE_THREADS) {
-        const uint32_t c = wcnt[w];
-        const uint32_t pos = wpos[w];
-        const int ws = wstart[w];
-        if (!(c & EXC_FLAG)) {
-            for (uint32_t j = 0; j < c; j++) run_out[pos + j] = sym_to_id(T, Sym<SymT>::widen(S[ws + j]));
-        }
-    }
-    if (n_exc) {  // rare: records in word order (one thread walks the tile's words)
-        if (tid == 0) {
-            uint64_t slot = s_misc[0];
-            for (int w = 0; w < nW; w++) {
-                if (!(wcnt[w] & EXC_FLAG)) continue;
-                if ((int64_t)slot < W.cap_exc) {
-                    ExcRec rec;
-                    const int ws = wstart[w], we = wstart[w + 1];
-                    rec.ws = t0 + ws;
-                    rec.tok_base = 0;
-                    rec.len = (we == 0xFFFF) ? -1 : (we - ws);
-                    rec.wpos = wpos[w];
-                    rec.cnt = 0;
-                    rec.tile = (uint32_t)tile;
-                    W.exc[slot] = rec;
-                } else {
-                    raise(A.err, HUTK_E_MEMORY);
-                }
-                slot++;
-            }
-        }
-    }
-    HUTK_STAMP(8);
-
-    // ---- 9. ids emitted before each document that starts in this tile ----------
-    for (int64_t d = dfirst + tid; d <= A.n_docs; d += TILE_THREADS) {
+    // ---- 8. ids emitted before each document that starts in this tile ----------
+    for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
         const int64_t o = A.offsets[d];
         if (o >= tile_end) break;
         if (o < t0) continue;
         const int r = (int)(o - t0);
-        const uint32_t widx = wpref[r >> 5] + __popc(wmask[r >> 5] & ((1u << (r & 31)) - 1u));
-        W.doc_tile_pos[d] = wpos[widx];
+        const int lr = r >> 4;
+        uint32_t before = lanepref[lr];
+        uint32_t fl = wmask16[lr] & ((1u << (r & 15)) - 1u);
+        for (; fl; fl &= fl - 1) {
+            const uint32_t c = M[16 * lr + __builtin_ctz(fl)];
+            if (c != EXC_MARK) before += c;
+        }
+        W.doc_tile_pos[d] = before;
     }
+    HUTK_STAMP(8);
     HUTK_STAMP(9);
 }
 
@@ -849,9 +975,10 @@ __global__ __launch_bounds__(1024) void k_scan(BatchArgs A, Workspace W) {
 // ------------------------------------------------------------------------
 // k_gather: tile runs and exception words -> ids_out
 // ------------------------------------------------------------------------
-constexpr int GATHER_EXC_LDS = 2048;
+constexpr int GATHER_EXC_LDS = 1024;  // >= TILE_BYTES: at most one exception word per byte
 
-__global__ __launch_bounds__(256) void k_gather(BatchArgs A, Workspace W) {
+constexpr int GATHER_THREADS = 64;
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspace W) {
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     const int tid = threadIdx.x;
@@ -865,11 +992,11 @@ __global__ __launch_bounds__(256) void k_gather(BatchArgs A, Workspace W) {
         return;
     }
     if (nexc == 0) {
-        for (uint32_t k = tid; k < dense; k += 256) A.ids_out[base + k] = run[k];
+        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = run[k];
         return;
     }
     const ExcRec* recs = W.exc + W.tile_exc_first[tile];
-    for (uint32_t e = tid; e < nexc; e += 256) e_pos[e] = recs[e].wpos;
+    for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) e_pos[e] = recs[e].wpos;
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
@@ -880,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_gather(BatchArgs A, Workspace W) {
         e_cum[nexc] = acc;
     }
     __syncthreads();
-    for (uint32_t k = tid; k < dense; k += 256) {
+    for (uint32_t k = tid; k < dense; k += GATHER_THREADS) {
         // exceptions that come before dense id k: those with wpos <= k
         uint32_t lo = 0, hi = nexc;
         while (lo < hi) {
@@ -894,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_gather(BatchArgs A, Workspace W) {
         if (r.tok_base < 0) continue;
         const int32_t* src = W.exc_tok + r.tok_base;
         const int64_t dst = base + r.wpos + e_cum[e];
-        for (uint32_t j = tid; j < r.cnt; j += 256) A.ids_out[dst + j] = src[j];
+        for (uint32_t j = tid; j < r.cnt; j += GATHER_THREADS) A.ids_out[dst + j] = src[j];
     }
 }
 
@@ -945,7 +1072,7 @@ void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, a, w);
 }
 void launch_gather(const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(256), 0, s, a, w);
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(GATHER_THREADS), 0, s, a, w);
 }
 void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const unsigned g = (unsigned)((a.n_docs + 1 + 255) / 256);

@@ -120,6 +120,7 @@ int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
  * mean shader cycles per phase over the first n_tiles tiles (out10[0] = their sum,
  * out10[k] = phase k).  Never enabled in timed runs. */
 int hutk_debug_profile(hutk_ctx* ctx, int enable);
+int hutk_debug_tile_bytes(void); /* input bytes per tile of the hot kernel */
 int hutk_debug_profile_read(hutk_ctx* ctx, int64_t n_tiles, double* out10);
 
 /* Per-call profiling events cost a little; they are on by default. */

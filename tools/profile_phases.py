@@ -29,9 +29,10 @@ dt = (time.perf_counter() - t) / 5
 print(f"{name} {n_docs} docs {len(d)/1e6:.1f} MB vocab {vocab}: {dt*1e3:.3f} ms/step  {len(d)/dt/1e9:.2f} GB/s  tile-kernel {ctx.last_timing()[0]:.3f} ms  ids {int(oo[-1])}")
 ctx.profile(True)
 run(); torch.cuda.synchronize()
-n_tiles = (len(d) + 2047) // 2048
+tb = _capi.load().hutk_debug_tile_bytes()
+n_tiles = (len(d) + tb - 1) // tb
 ph = ctx.profile_read(n_tiles)
-names = ["total", "1 stage+docs", "2 codes", "3 flags", "4 wordlist+pairs", "5 classify+sort", "6 merge", "7 scan", "8 write", "9 docpos"]
+names = ["total", "1 stage+docs", "2 classify", "3 byte pairs", "4 bucket words", "5 merge", "6 scan+meta", "7 write ids", "8 docpos", "9 -"]
 for nme, v in zip(names, ph):
     print(f"  {nme:18s} {v:10.0f} cyc  {100*v/ph[0]:5.1f}%")
 ctx.profile(False)
