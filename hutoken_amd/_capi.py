@@ -125,7 +125,7 @@ class Context:
         import numpy as np
         out = np.zeros(8, dtype=np.int64)
         raise_for(load().hutk_table_stats(self._h, out.ctypes.data))
-        keys = ["n_keys", "n_vocab_sym", "n_sym", "n_pairs", "pair_slots", "rank_is_sym", "ident_ids", "n_prefix"]
+        keys = ["n_keys", "n_vocab_sym", "n_sym", "n_pairs", "pair_slots", "rank_is_sym", "ident_ids", "n_word_entries"]
         return dict(zip(keys, out.tolist()))
 
     def encode_packed(self, data, offsets, want_status=True):

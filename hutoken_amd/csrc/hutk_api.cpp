@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -66,6 +67,9 @@ struct hutk_ctx {
     DevBuf<uint32_t> d_item_sym, d_prefix_syms;
     DevBuf<uint8_t> d_item_direct;
     DevBuf<uint16_t> d_bytepair16;
+    DevBuf<uint4> d_word_keys;
+    DevBuf<uint32_t> d_word_syms;
+    int64_t n_word_entries = 0;
     DevBuf<uint32_t> d_bytepair32;
     DevBuf<long long> w_prof;
     bool profile = false;
@@ -112,9 +116,8 @@ int upload_tables(hutk_ctx* c) {
     HIP_TRY(c->d_prefix_alone.reserve(EXC_LDS_UNITS));
 
     DevTables& D = c->dt;
-    D.pair_slots = c->d_pair.p;
+    D.pair_slots = reinterpret_cast<const uint2*>(c->d_pair.p);
     D.pair_mask = T.pair_mask;
-    D.pair_shift = T.pair_shift;
     D.sym_id = c->d_sym_id.p;
     D.n_vocab_sym = T.n_vocab_sym;
     D.n_sym = T.n_sym;
@@ -133,6 +136,9 @@ int upload_tables(hutk_ctx* c) {
     D.ident_ids = T.ident_ids;
     D.sym16 = T.sym16;
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
+    D.word_keys = nullptr;
+    D.word_syms = nullptr;
+    D.word_mask = 0;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
@@ -209,6 +215,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_item_direct.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
+        c->d_word_keys.release(); c->d_word_syms.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_err.release();
@@ -219,6 +226,49 @@ void destroy(hutk_ctx* c) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
+}
+
+// Whole-word table (byte-encoder mode, no prefix).  Every vocabulary key that can be
+// written in raw input bytes (<= 16) is pushed through the device pipeline as a document
+// of its own; the ones that come back as exactly their own id become table entries.
+// Nothing is assumed about the vocabulary: the merge kernel itself is the judge.
+int build_word_table(hutk_ctx* c) {
+    Tables& T = c->tab;
+    const size_t n = T.cand_sym.size();
+    if (!n) return HUTK_OK;
+    std::vector<int64_t> offs(n + 1), oo(n + 1);
+    for (size_t i = 0; i <= n; i++) offs[i] = T.cand_off[i];
+    std::vector<int32_t> ids(T.cand_bytes.size() + 1);
+    int rc = hutk_encode_batch(c, T.cand_bytes.data(), offs.data(), (int64_t)n, ids.data(), (int64_t)ids.size(),
+                               oo.data(), nullptr);
+    if (rc) return rc;
+    std::vector<size_t> keep;
+    for (size_t i = 0; i < n; i++)
+        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
+            keep.push_back(i);
+    if (keep.empty()) return HUTK_OK;
+    uint32_t cap = 1024;
+    while (cap < keep.size() * 2 + 16) cap <<= 1;
+    std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
+    std::vector<uint32_t> syms(cap, 0);
+    for (size_t i : keep) {
+        uint32_t k[4] = {0, 0, 0, 0};
+        const size_t len = (size_t)(offs[i + 1] - offs[i]);
+        for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
+        uint32_t h = word_hash(k[0], k[1], k[2], k[3]) & (cap - 1);
+        while (keys[h].x != 0) h = (h + 1) & (cap - 1);
+        keys[h] = make_uint4(k[0], k[1], k[2], k[3]);
+        syms[h] = T.cand_sym[i];
+    }
+    HIP_TRY(c->d_word_keys.reserve(cap));
+    HIP_TRY(c->d_word_syms.reserve(cap));
+    HIP_TRY(hipMemcpy(c->d_word_keys.p, keys.data(), cap * sizeof(uint4), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_word_syms.p, syms.data(), cap * 4, hipMemcpyHostToDevice));
+    c->dt.word_keys = c->d_word_keys.p;
+    c->dt.word_syms = c->d_word_syms.p;
+    c->dt.word_mask = cap - 1;
+    c->n_word_entries = (int64_t)keep.size();
+    return HUTK_OK;
 }
 
 }  // namespace
@@ -273,6 +323,7 @@ int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_
         for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
         if (!ok) { rc = set_err(HUTK_E_DEVICE, "hipEventCreate failed"); break; }
         rc = upload_tables(c);
+        if (rc == HUTK_OK && !getenv("HUTK_NO_WORD_TABLE")) rc = build_word_table(c);
     } while (0);
     if (rc) {
         std::string keep = g_err;
@@ -308,7 +359,7 @@ int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8) {
     out8[4] = (int64_t)T.pair_slots.size();
     out8[5] = T.rank_is_sym;
     out8[6] = T.ident_ids;
-    out8[7] = (int64_t)T.prefix_syms.size();
+    out8[7] = ctx->n_word_entries;
     return HUTK_OK;
 }
 

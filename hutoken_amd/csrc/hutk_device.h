@@ -25,8 +25,8 @@ constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units me
 enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE = 4, C_WS = 5, C_BAD = 6 };
 
 struct DevTables {
-    const uint64_t* pair_slots;
-    uint32_t pair_mask, pair_shift;
+    const uint2* pair_slots;  // x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8
+    uint32_t pair_mask;
     const int32_t* sym_id;
     uint32_t n_vocab_sym, n_sym;
     const uint32_t* item_sym;    // [256]
@@ -42,6 +42,11 @@ struct DevTables {
     // [b1 << 8 | b2], stored as uint16 when sym16 else uint32 (SYM_NONE when unranked)
     const void* bytepair;
     int32_t sym16;  // every symbol < 0xFFF0: LDS arrays hold 16-bit symbols
+    // whole-word table (byte-encoder mode): 16 raw bytes, zero padded -> symbol of the one
+    // token the word encodes to.  word_mask == 0: no table.  Empty slot: keys[i].x == 0.
+    const uint4* word_keys;
+    const uint32_t* word_syms;
+    uint32_t word_mask;
 };
 
 // one word the tile kernel hands to the exception kernel

@@ -24,16 +24,33 @@ constexpr uint32_t SYM_UNK = (1u << SYM_BITS) - 1;  // unit that is no symbol: n
 constexpr uint32_t SYM_NONE = 0xFFFFFFFFu;          // "this pair has no rank"
 constexpr uint64_t SLOT_EMPTY = ~0ull;
 
-// pair table slot: [left:20][right:20][merged:20] in the low 60 bits
+// pair table slot = two dwords (little-endian halves of one uint64):
+//   w0 = left | (right & 0xFFF) << 20        w1 = right >> 12 | merged << 8
+// so a probe compares 32-bit words only.  An empty slot is all ones (left = SYM_UNK
+// is never a key).
 static inline uint64_t pair_slot(uint32_t l, uint32_t r, uint32_t m) {
-    return ((uint64_t)l << 40) | ((uint64_t)r << 20) | m;
+    const uint32_t w0 = l | ((r & 0xFFFu) << 20), w1 = (r >> 12) | (m << 8);
+    return (uint64_t)w0 | ((uint64_t)w1 << 32);
 }
 
 // The same mixing function on host (table build) and device (lookup).
+// 24-bit multiplies (full rate on CDNA) and xor-shifts; the slot index is the LOW bits
 HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) {
-    uint32_t h = l * 0x9E3779B1u ^ (r * 0x85EBCA77u + 0x165667B1u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t h = __umul24(l, 0x9E3779u) ^ (__umul24(r, 0x85EBCBu) + 0x165667B1u);
+#else
+    uint32_t h = (uint32_t)((uint64_t)(l & 0xFFFFFFu) * 0x9E3779u) ^
+                 ((uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x85EBCBu) + 0x165667B1u);
+#endif
     h ^= h >> 15;
-    return h * 0x2C1B3C6Du;
+    h ^= h >> 7;
+    return h;
+}
+// whole-word table: 16 raw bytes (zero padded) as four dwords
+HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    uint32_t x = k0 ^ ((k1 << 13) | (k1 >> 19)) ^ ((k2 << 7) | (k2 >> 25)) ^ ((k3 << 21) | (k3 >> 11));
+    x *= 0x9E3779B1u;
+    return x ^ (x >> 15);
 }
 HUTK_HD uint32_t char_hash(uint32_t packed) {
     uint32_t h = packed * 0x9E3779B1u;
@@ -56,7 +73,6 @@ struct Tables {
     // (left, right) -> merged symbol, open addressing, linear probing
     std::vector<uint64_t> pair_slots;
     uint32_t pair_mask = 0;
-    uint32_t pair_shift = 0;  // 32 - log2(capacity)
     int64_t n_pairs = 0;
 
     // initial symbol of a source item
@@ -75,6 +91,13 @@ struct Tables {
     bool sym16 = false;
     std::vector<uint32_t> bytepair32;
     std::vector<uint16_t> bytepair16;
+
+    // byte-encoder mode without prefix: vocabulary keys expressed in raw input bytes
+    // (<= 16), candidates for the whole-word table.  A candidate enters the table only
+    // after the device pipeline itself has encoded it to exactly its own id.
+    std::vector<uint8_t> cand_bytes;   // concatenated
+    std::vector<uint32_t> cand_off;    // [n+1]
+    std::vector<uint32_t> cand_sym;    // [n]
 
     bool is_byte_encoder = false;
     bool has_prefix = false;

@@ -46,15 +46,20 @@ namespace hutk {
 // ------------------------------------------------------------------------
 // table lookups
 // ------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, uint32_t r) {
-    const uint64_t key = ((uint64_t)l << 20) | r;
-    uint32_t h = pair_hash(l, r) >> T.pair_shift;
+// pair slot: x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8 (hutk_internal.h)
+__device__ __forceinline__ uint32_t pair_resolve(const DevTables& T, uint2 s, uint32_t l, uint32_t r, uint32_t h) {
+    const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
     for (;;) {
-        const uint64_t s = T.pair_slots[h];
-        if ((s >> 20) == key) return (uint32_t)s & 0xFFFFFu;
-        if (s == SLOT_EMPTY) return SYM_NONE;
+        // empty first: (SYM_UNK, SYM_UNK) has the same bit pattern as an empty slot
+        if (s.x == 0xFFFFFFFFu) return SYM_NONE;
+        if (s.x == k0 && (s.y & 0xFFu) == k1) return s.y >> 8;
         h = (h + 1) & T.pair_mask;
+        s = T.pair_slots[h];
     }
+}
+__device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, uint32_t r) {
+    const uint32_t h = pair_hash(l, r) & T.pair_mask;
+    return pair_resolve(T, T.pair_slots[h], l, r, h);
 }
 
 __device__ __forceinline__ uint32_t char_lookup(const DevTables& T, uint32_t packed) {
@@ -166,6 +171,9 @@ __device__ __forceinline__ bool word_starts(const uint8_t* scode, const uint32_t
 // symbol storage in LDS: 16-bit when the vocabulary has fewer than 65520 symbols
 // (halves the LDS footprint of the tile kernel -> more resident wavefronts)
 // ------------------------------------------------------------------------
+// With fewer than 0xFFF0 symbols the 16-bit form of a symbol is just its low half:
+// SYM_NONE -> 0xFFFF ("no rank" in the pair array), SYM_UNK -> 0xFFFF (a unit that is no
+// symbol: no table key has it, and it maps to id -1), so narrow/widen are plain casts.
 template <typename SymT> struct Sym;
 template <> struct Sym<uint32_t> {
     static __device__ __forceinline__ uint32_t narrow(uint32_t v) { return v; }
@@ -173,35 +181,10 @@ template <> struct Sym<uint32_t> {
     static constexpr uint32_t NONE = SYM_NONE;
 };
 template <> struct Sym<uint16_t> {
-    // SYM_NONE -> 0xFFFF, SYM_UNK -> 0xFFFE
-    static __device__ __forceinline__ uint16_t narrow(uint32_t v) {
-        return v == SYM_NONE ? (uint16_t)0xFFFFu : v == SYM_UNK ? (uint16_t)0xFFFEu : (uint16_t)v;
-    }
-    static __device__ __forceinline__ uint32_t widen(uint16_t v) {
-        return v == 0xFFFFu ? SYM_NONE : v == 0xFFFEu ? SYM_UNK : (uint32_t)v;
-    }
+    static __device__ __forceinline__ uint16_t narrow(uint32_t v) { return (uint16_t)v; }
+    static __device__ __forceinline__ uint32_t widen(uint16_t v) { return (uint32_t)v; }
     static constexpr uint16_t NONE = 0xFFFFu;
 };
-
-// two independent lookups: both first probes are issued before either is examined,
-// so their latencies overlap (the left and right neighbour of a fresh merge)
-__device__ __forceinline__ uint32_t pair_resolve(const DevTables& T, uint64_t s, uint64_t key, uint32_t h) {
-    for (;;) {
-        if ((s >> 20) == key) return (uint32_t)s & 0xFFFFFu;
-        if (s == SLOT_EMPTY) return SYM_NONE;
-        h = (h + 1) & T.pair_mask;
-        s = T.pair_slots[h];
-    }
-}
-__device__ __forceinline__ void pair_lookup2(const DevTables& T, bool on1, uint32_t l1, uint32_t r1, bool on2,
-                                             uint32_t l2, uint32_t r2, uint32_t& m1, uint32_t& m2) {
-    const uint32_t h1 = pair_hash(l1, r1) >> T.pair_shift;
-    const uint32_t h2 = pair_hash(l2, r2) >> T.pair_shift;
-    const uint64_t s1 = on1 ? T.pair_slots[h1] : SLOT_EMPTY;
-    const uint64_t s2 = on2 ? T.pair_slots[h2] : SLOT_EMPTY;
-    m1 = on1 ? pair_resolve(T, s1, ((uint64_t)l1 << 20) | r1, h1) : SYM_NONE;
-    m2 = on2 ? pair_resolve(T, s2, ((uint64_t)l2 << 20) | r2, h2) : SYM_NONE;
-}
 
 // 64 bits of a bitmap starting at bit `start` (the bitmap has 2 words of slack)
 __device__ __forceinline__ uint64_t bits64(const uint32_t* m, int start) {
@@ -209,55 +192,6 @@ __device__ __forceinline__ uint64_t bits64(const uint32_t* m, int start) {
     uint64_t v = ((uint64_t)m[k] | ((uint64_t)m[k + 1] << 32)) >> sh;
     if (sh) v |= (uint64_t)m[k + 2] << (64 - sh);
     return v;
-}
-
-// ------------------------------------------------------------------------
-// merge loop, one lane per word, arrays in LDS (src/core.c:66-209)
-//   Sw[0..n): symbols;  Mw[i]: merged symbol of (live unit i, next live unit)
-//   cand: bit i set <=> Mw[i] holds a rank (initial pairs are ranked before the call)
-// returns the number of surviving symbols, compacted to Sw[0..cnt)
-// ------------------------------------------------------------------------
-template <typename SymT>
-__device__ int bpe_lane(const DevTables& T, SymT* Sw, SymT* Mw, int n, uint64_t cand) {
-    if (n <= 1) return n;
-    uint64_t live = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    while (cand) {
-        uint32_t best = 0xFFFFFFFFu;
-        int p = 0;
-        for (uint64_t c = cand; c; c &= c - 1) {
-            const int i = __builtin_ctzll(c);
-            const uint32_t r = rank_of(T, Sym<SymT>::widen(Mw[i]));
-            if (r < best) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
-                best = r;
-                p = i;
-            }
-        }
-        const int q = p + 1 + __builtin_ctzll(live >> (p + 1));
-        const SymT merged_n = Mw[p];
-        const uint32_t merged = Sym<SymT>::widen(merged_n);
-        Sw[p] = merged_n;
-        live &= ~(1ull << q);
-        cand &= ~((1ull << q) | (1ull << p));
-        const uint64_t right = (q >= 63) ? 0ull : (live >> (q + 1));
-        const uint64_t left = live & ((1ull << p) - 1ull);
-        const int q2 = right ? q + 1 + __builtin_ctzll(right) : 0;
-        const int p0 = left ? 63 - __builtin_clzll(left) : 0;
-        uint32_t mr, ml;
-        pair_lookup2(T, right != 0, merged, right ? Sym<SymT>::widen(Sw[q2]) : 0u, left != 0,
-                     left ? Sym<SymT>::widen(Sw[p0]) : 0u, merged, mr, ml);
-        if (right) {
-            Mw[p] = Sym<SymT>::narrow(mr);
-            if (mr != SYM_NONE) cand |= 1ull << p;
-        }
-        if (left) {
-            Mw[p0] = Sym<SymT>::narrow(ml);
-            if (ml != SYM_NONE) cand |= 1ull << p0;
-            else cand &= ~(1ull << p0);
-        }
-    }
-    int cnt = 0;
-    for (uint64_t c = live; c; c &= c - 1) Sw[cnt++] = Sw[__builtin_ctzll(c)];
-    return cnt;
 }
 
 // ------------------------------------------------------------------------
@@ -307,7 +241,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return inc - v;
 }
 
-template <typename SymT, bool BYTE_MODE>
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM>
 __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
     __shared__ uint32_t docm[WINDOW / 32 + 3];
@@ -315,6 +249,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ __attribute__((aligned(8))) uint16_t rmask16[64 + 8];  // pair (r, r+1) has a rank
     __shared__ uint32_t lanepref[64];                                  // ids before lane l's positions
     __shared__ uint16_t order[TILE_BYTES];                              // lane words, longest first: ws | n << 10
+    __shared__ uint16_t wlist[TILE_BYTES];                              // word starts of the tile, in order
+    __shared__ uint32_t missbits[(TILE_BYTES + 31) / 32];               // word index -> goes to the merge loop
     __shared__ __attribute__((aligned(16))) SymT S[NPOS];
     __shared__ __attribute__((aligned(16))) SymT M[NPOS];
     __shared__ SymT s_item_sym[256];
@@ -324,6 +260,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
 
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
+    auto RK = [&](uint32_t merged) -> uint32_t {  // rank used in comparisons
+        if (RANK_IS_SYM) return merged;
+        return (uint32_t)T.sym_id[merged] ^ 0x80000000u;  // signed id order as unsigned
+    };
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
     const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
@@ -413,7 +353,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __syncthreads();
     HUTK_STAMP(3);
 
-    // ---- 5. words of this lane's positions: unit counts, histogram, order ---------
+    // ---- 5. word list; whole-word table; bucket the remaining words by unit count ----
     const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
     uint32_t own = flags;                    // starts that are words of this tile
     {
@@ -421,10 +361,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (lo >= limit) own = 0;
         else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
     }
-    uint32_t excbits = 0;  // own starts that became exception words
-    for (uint32_t m = own; m; m &= m - 1) {
-        const int j = __builtin_ctz(m);
-        const int ws = 16 * lane + j;
+    uint32_t nW;
+    {
+        uint32_t at = wave_excl_scan(__popc(own), lane, &nW);
+        for (uint32_t m = own; m; m &= m - 1) wlist[at++] = (uint16_t)(16 * lane + __builtin_ctz(m));
+    }
+    if (lane < (TILE_BYTES + 31) / 32) missbits[lane] = 0;
+    __syncthreads();
+    for (uint32_t wi = lane; wi < nW; wi += 64) {
+        const int ws = wlist[wi];
         // end of the word: the next start bit within 63 positions (bits beyond the
         // window are ones, which is only true when the data ends there)
         const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
@@ -463,11 +408,45 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             if (n > LANE_MAX_UNITS) exc = true;
         }
         if (exc) {
-            excbits |= 1u << j;
             M[ws] = (SymT)EXC_MARK;
-        } else {
-            atomicAdd(&hist[n], 1u);
+            continue;
         }
+        if (BYTE_MODE && T.word_mask && nb <= 16 && nb > 1) {
+            // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
+            // token it encodes to.  Entries were verified by this pipeline at context creation.
+            const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
+            const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
+            const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
+            uint32_t k0 = q0, k1 = q1, k2 = q2, k3 = q3;
+            if (o8) {
+                k0 = funnel_r(q1, q0, o8);
+                k1 = funnel_r(q2, q1, o8);
+                k2 = funnel_r(q3, q2, o8);
+                k3 = funnel_r(q4, q3, o8);
+            }
+            // zero the bytes at and beyond nb
+            const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
+            const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
+            if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
+            else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
+            else if (full == 2) { k2 &= keep; k3 = 0; }
+            else { k3 &= keep; }
+            uint32_t h = word_hash(k0, k1, k2, k3) & T.word_mask;
+            bool hit = false;
+            for (;;) {
+                const uint4 key = T.word_keys[h];
+                if (key.x == k0 && key.y == k1 && key.z == k2 && key.w == k3) { hit = true; break; }
+                if (key.x == 0) break;
+                h = (h + 1) & T.word_mask;
+            }
+            if (hit) {
+                S[ws] = Sym<SymT>::narrow(T.word_syms[h]);
+                M[ws] = (SymT)1;
+                continue;
+            }
+        }
+        atomicAdd(&hist[n], 1u);
+        atomicOr(&missbits[wi >> 5], 1u << (wi & 31));
     }
     __syncthreads();
     {  // longest first: bucket n starts after all longer buckets
@@ -481,9 +460,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     hist[lane] = 0;
     if (lane == 0) s_next = 64;
     __syncthreads();
-    for (uint32_t m = own & ~excbits; m; m &= m - 1) {
-        const int j = __builtin_ctz(m);
-        const int ws = 16 * lane + j;
+    for (uint32_t wi = lane; wi < nW; wi += 64) {
+        if (!((missbits[wi >> 5] >> (wi & 31)) & 1u)) continue;
+        const int ws = wlist[wi];
         const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
         int n = nb;
         if (!BYTE_MODE) {  // units = characters = lead bytes
@@ -538,7 +517,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     for (uint32_t c = cand; c; c &= c - 1) {
                         const int i = __builtin_ctz(c);
                         const SymT mv = M[ws + i];
-                        const uint32_t r = rank_of(T, Sym<SymT>::widen(mv));
+                        const uint32_t r = RK(Sym<SymT>::widen(mv));
                         if (r < br) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
                             br = r;
                             bp = i;
@@ -567,17 +546,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
                 const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
                 // issue both first probes
-                const uint32_t h1 = pair_hash(merged, sr) >> T.pair_shift;
-                const uint32_t h2 = pair_hash(sl, merged) >> T.pair_shift;
-                const uint64_t s1 = right ? T.pair_slots[h1] : SLOT_EMPTY;
-                const uint64_t s2 = left ? T.pair_slots[h2] : SLOT_EMPTY;
+                const uint32_t h1 = pair_hash(merged, sr) & T.pair_mask;
+                const uint32_t h2 = pair_hash(sl, merged) & T.pair_mask;
+                const uint2 s1 = T.pair_slots[right ? h1 : 0u];  // unconditional loads: no exec juggling
+                const uint2 s2 = T.pair_slots[left ? h2 : 0u];
                 // rescan what the merge did not touch
                 if (left) cand &= ~(1u << p0);
                 br = 0xFFFFFFFFu;
                 for (uint32_t c = cand; c; c &= c - 1) {
                     const int i = __builtin_ctz(c);
                     const SymT mv = Mw[i];
-                    const uint32_t r = rank_of(T, Sym<SymT>::widen(mv));
+                    const uint32_t r = RK(Sym<SymT>::widen(mv));
                     if (r < br) {
                         br = r;
                         bp = i;
@@ -585,14 +564,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     }
                 }
                 // the two new pairs
-                const uint32_t mr = right ? pair_resolve(T, s1, ((uint64_t)merged << 20) | sr, h1) : SYM_NONE;
-                const uint32_t ml = left ? pair_resolve(T, s2, ((uint64_t)sl << 20) | merged, h2) : SYM_NONE;
+                const uint32_t mr = right ? pair_resolve(T, s1, merged, sr, h1) : SYM_NONE;
+                const uint32_t ml = left ? pair_resolve(T, s2, sl, merged, h2) : SYM_NONE;
                 if (right) {
                     const SymT mn = Sym<SymT>::narrow(mr);
                     Mw[p] = mn;
                     if (mr != SYM_NONE) {
                         cand |= 1u << p;
-                        const uint32_t r = rank_of(T, mr);
+                        const uint32_t r = RK(mr);
                         if (r < br || (r == br && p < bp)) {
                             br = r;
                             bp = p;
@@ -605,7 +584,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     Mw[p0] = mn;
                     if (ml != SYM_NONE) {
                         cand |= 1u << p0;
-                        const uint32_t r = rank_of(T, ml);
+                        const uint32_t r = RK(ml);
                         if (r < br || (r == br && p0 < bp)) {
                             br = r;
                             bp = p0;
@@ -1056,13 +1035,19 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s) {
 }
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const dim3 g((unsigned)a.n_tiles), b(TILE_THREADS);
-    if (t.sym16) {
-        if (t.is_byte_encoder) hipLaunchKernelGGL((k_tiles<uint16_t, true>), g, b, 0, s, t, a, w);
-        else hipLaunchKernelGGL((k_tiles<uint16_t, false>), g, b, 0, s, t, a, w);
-    } else {
-        if (t.is_byte_encoder) hipLaunchKernelGGL((k_tiles<uint32_t, true>), g, b, 0, s, t, a, w);
-        else hipLaunchKernelGGL((k_tiles<uint32_t, false>), g, b, 0, s, t, a, w);
+#define HUTK_LAUNCH(ST, BM, RS) hipLaunchKernelGGL((k_tiles<ST, BM, RS>), g, b, 0, s, t, a, w)
+    const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
+    switch (variant) {
+        case 7: HUTK_LAUNCH(uint16_t, true, true); break;
+        case 6: HUTK_LAUNCH(uint16_t, true, false); break;
+        case 5: HUTK_LAUNCH(uint16_t, false, true); break;
+        case 4: HUTK_LAUNCH(uint16_t, false, false); break;
+        case 3: HUTK_LAUNCH(uint32_t, true, true); break;
+        case 2: HUTK_LAUNCH(uint32_t, true, false); break;
+        case 1: HUTK_LAUNCH(uint32_t, false, true); break;
+        default: HUTK_LAUNCH(uint32_t, false, false); break;
     }
+#undef HUTK_LAUNCH
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     // fixed grid; every wavefront pulls records until the device counter runs out

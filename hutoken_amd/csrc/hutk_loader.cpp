@@ -335,14 +335,12 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     T.n_pairs = (int64_t)entries.size();
     {
         uint32_t cap = pow2_at_least(entries.size() * 2 + 16);
-        uint32_t lg = 0;
-        while ((1u << lg) < cap) lg++;
         T.pair_mask = cap - 1;
-        T.pair_shift = 32 - lg;
         T.pair_slots.assign(cap, SLOT_EMPTY);
         for (uint64_t en : entries) {
-            uint32_t l = (uint32_t)(en >> 40), r = (uint32_t)((en >> 20) & 0xFFFFF);
-            uint32_t h = pair_hash(l, r) >> T.pair_shift;
+            const uint32_t w0 = (uint32_t)en, w1 = (uint32_t)(en >> 32);
+            const uint32_t l = w0 & 0xFFFFFu, r = (w0 >> 20) | ((w1 & 0xFFu) << 12);
+            uint32_t h = pair_hash(l, r) & T.pair_mask;
             while (T.pair_slots[h] != SLOT_EMPTY) h = (h + 1) & T.pair_mask;
             T.pair_slots[h] = en;
         }
@@ -352,12 +350,12 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     T.sym16 = T.n_sym < 0xFFF0u;
     if (is_byte_encoder) {
         auto host_lookup = [&](uint32_t l, uint32_t r) -> uint32_t {
-            const uint64_t key = ((uint64_t)l << 20) | r;
-            uint32_t h = pair_hash(l, r) >> T.pair_shift;
+            const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
+            uint32_t h = pair_hash(l, r) & T.pair_mask;
             for (;;) {
                 const uint64_t sl = T.pair_slots[h];
-                if ((sl >> 20) == key) return (uint32_t)sl & 0xFFFFFu;
-                if (sl == SLOT_EMPTY) return SYM_NONE;
+                if ((uint32_t)sl == 0xFFFFFFFFu) return SYM_NONE;
+                if ((uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1) return (uint32_t)(sl >> 40);
                 h = (h + 1) & T.pair_mask;
             }
         };
@@ -368,6 +366,38 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
                 if (m == SYM_NONE) continue;
                 if (T.sym16) T.bytepair16[(b1 << 8) | b2] = (uint16_t)m; else T.bytepair32[(b1 << 8) | b2] = m;
             }
+    }
+
+    // ---- byte-encoder mode: keys as raw input bytes (whole-word table candidates) ----
+    if (is_byte_encoder && !T.has_prefix) {
+        // unit string -> the one input byte that produces it (ambiguous units disable the table)
+        std::unordered_map<uint32_t, int> byte_of_sym;
+        bool ambiguous = false;
+        for (int b = 1; b < 256; b++) {
+            auto ins = byte_of_sym.emplace(T.item_sym[b], b);
+            if (!ins.second) ambiguous = true;
+        }
+        T.cand_off.push_back(0);
+        if (!ambiguous) {
+            std::vector<std::string> us;
+            for (size_t i = 0; i < order.size(); i++) {
+                const std::string& k = *order[i].second;
+                if (!split_units(k, true, us) || us.empty() || us.size() > 16) continue;
+                std::string raw;
+                bool ok = true;
+                for (auto& u : us) {
+                    auto it = sym_of.find(u);
+                    if (it == sym_of.end()) { ok = false; break; }
+                    auto bt = byte_of_sym.find(it->second);
+                    if (bt == byte_of_sym.end()) { ok = false; break; }
+                    raw.push_back((char)bt->second);
+                }
+                if (!ok) continue;
+                T.cand_bytes.insert(T.cand_bytes.end(), raw.begin(), raw.end());
+                T.cand_off.push_back((uint32_t)T.cand_bytes.size());
+                T.cand_sym.push_back((uint32_t)i);
+            }
+        }
     }
 
     // ---- non-byte mode: multi-byte character -> symbol ----

@@ -105,7 +105,7 @@ int64_t hutk_vocab_size(const hutk_ctx* ctx);      /* distinct keys loaded */
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx);
 int hutk_device_ordinal(const hutk_ctx* ctx);
 /* out8: distinct keys, vocabulary symbols, symbols, pair entries, pair slots,
- * rank_is_sym, ident_ids, prefix units.  Passing device = -2 to hutk_ctx_create
+ * rank_is_sym, ident_ids, whole-word table entries.  Passing device = -2 to hutk_ctx_create
  * builds a host-only context (tables, no GPU) for this kind of inspection;
  * encode calls on it fail with HUTK_E_DEVICE. */
 int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8);
