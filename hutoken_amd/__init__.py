@@ -33,7 +33,6 @@ _BAD_INIT_ARGS = ("Invalid arguments. Expected a string "
                   "optional integer (special_token_id), "
                   " an optional string (regex_pattern) and"
                   "a string or None (merges_file_path)")
-_WORD_TOO_LARGE = "A single word in the input text is too large to be processed."
 
 # process-global context, like the reference's global_encode_context (lib.c:73-74)
 _ctx = None
@@ -127,9 +126,8 @@ def _native_batch_encode(texts, num_threads=1):
     data, offs = _pack(texts)
     if num_threads <= 0:
         return [[] for _ in texts]  # no worker starts (lib.c:784-791)
-    ids, oo, _st, rc = _ctx.encode_packed(data, offs)
-    if rc == _capi.E_WORD_TOO_LARGE:
-        raise RuntimeError(_WORD_TOO_LARGE)  # lib.c:796-808
+    # an over-long word ends its document silently, as in the reference (core.c:503)
+    ids, oo, _st, _rc = _ctx.encode_packed(data, offs)
     flat = ids.tolist()
     bounds = oo.tolist()
     return [flat[bounds[i]:bounds[i + 1]] for i in range(len(texts))]
@@ -157,9 +155,7 @@ def encode_packed(data, offsets):
     batch_encode."""
     if _ctx is None:
         raise RuntimeError(_NOT_INIT)
-    ids, oo, st, rc = _ctx.encode_packed(data, offsets)
-    if rc == _capi.E_WORD_TOO_LARGE:
-        raise RuntimeError(_WORD_TOO_LARGE)
+    ids, oo, st, _rc = _ctx.encode_packed(data, offsets)
     return ids, oo, st
 
 
@@ -184,9 +180,7 @@ def encode_packed_device(d_bytes, d_offsets, check=True):
                        oo.data_ptr(), 0, err.data_ptr(), stream)
     if check:
         code = int(err.item())
-        if code == _capi.E_WORD_TOO_LARGE:
-            raise RuntimeError(_WORD_TOO_LARGE)
-        if code != 0:
+        if code not in (0, _capi.E_WORD_TOO_LARGE):
             raise RuntimeError(f"hutoken_amd: device-side error {code}")
     return ids, oo
 

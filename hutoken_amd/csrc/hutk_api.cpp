@@ -487,13 +487,39 @@ int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets,
     if (status && n_docs)
         HIP_TRY(hipMemcpyAsync(status, c->s_status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const int64_t total = out_offsets[n_docs];
+    int64_t total = out_offsets[n_docs];
     if (total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
     if (total) HIP_TRY(hipMemcpy(ids_out, c->s_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    if (err == HUTK_E_WORD_TOO_LARGE) {
+        // The reference ends a document at a word longer than 262144 bytes and reports nothing
+        // (core.c:402-407 sets error_msg, core.c:503 clears it): drop the ids that follow the
+        // first such word of each affected document.  Rare; done here on the outputs.
+        uint32_t n_exc = 0;
+        HIP_TRY(hipMemcpy(&n_exc, c->w_counters.p, 4, hipMemcpyDeviceToHost));
+        std::vector<ExcRec> recs(n_exc);
+        if (n_exc) HIP_TRY(hipMemcpy(recs.data(), c->w_exc.p, n_exc * sizeof(ExcRec), hipMemcpyDeviceToHost));
+        std::vector<int64_t> keep((size_t)n_docs, -1);  // ids kept per cut document
+        for (auto& r : recs) {
+            if (r.tok_base >= 0) continue;
+            const int64_t d = (std::upper_bound(offsets, offsets + n_docs + 1, r.ws) - offsets) - 1;
+            if (d < 0 || d >= n_docs) continue;
+            const int64_t k = r.out_pos - out_offsets[d];
+            if (keep[d] < 0 || k < keep[d]) keep[d] = k;
+        }
+        int64_t w = 0;
+        for (int64_t d = 0; d < n_docs; d++) {
+            const int64_t a = out_offsets[d], b = out_offsets[d + 1];
+            const int64_t len = keep[d] >= 0 ? keep[d] : b - a;
+            if (w != a && len) memmove(ids_out + w, ids_out + a, (size_t)len * 4);
+            out_offsets[d] = w;
+            w += len;
+            if (status && keep[d] >= 0) status[d] = HUTK_DOC_WORD_TOO_LARGE;
+        }
+        out_offsets[n_docs] = w;
+        return HUTK_OK;
+    }
     switch (err) {
         case HUTK_OK: return HUTK_OK;
-        case HUTK_E_WORD_TOO_LARGE:
-            return set_err(err, "A single word in the input text is too large to be processed.");
         case HUTK_E_NUL_BYTE: return set_err(err, "a document contains a 0x00 byte");
         case HUTK_E_INVALID_UTF8: return set_err(err, "text is not valid UTF-8 (non-byte-encoder mode)");
         case HUTK_E_CAPACITY: return set_err(err, "ids_cap too small");
@@ -507,33 +533,7 @@ int hutk_encode(hutk_ctx* c, const uint8_t* text, int64_t len, int32_t* ids_out,
     int64_t offsets[2] = {0, len};
     int64_t oo[2] = {0, 0};
     int32_t st = 0;
-    int rc = hutk_encode_batch(c, text, offsets, 1, ids_out, ids_cap, oo, &st);
-    if (rc == HUTK_E_WORD_TOO_LARGE) {
-        // hutoken.encode() ignores the error and returns the ids produced before the
-        // offending word (lib.c:692-697): encode the text up to that word.  The cut
-        // position comes back through the exception record of the word.
-        int64_t cut = -1;
-        const uint32_t* cnt = c->w_counters.p;
-        uint32_t n_exc = 0;
-        if (hipMemcpy(&n_exc, cnt, 4, hipMemcpyDeviceToHost) == hipSuccess) {
-            std::vector<ExcRec> recs(n_exc);
-            if (n_exc && hipMemcpy(recs.data(), c->w_exc.p, n_exc * sizeof(ExcRec), hipMemcpyDeviceToHost) == hipSuccess)
-                for (auto& r : recs)
-                    if (r.tok_base < 0) {
-                        const int64_t at = -(r.tok_base + 1);
-                        if (cut < 0 || at < cut) cut = at;
-                    }
-        }
-        if (cut >= 0) {
-            offsets[1] = cut;
-            int rc2 = hutk_encode_batch(c, text, offsets, 1, ids_out, ids_cap, oo, nullptr);
-            if (rc2) return rc2;
-            *n_ids = oo[1];
-            if (status) *status = HUTK_DOC_WORD_TOO_LARGE;
-            g_err = "A single word in the input text is too large to be processed.";
-            return HUTK_E_WORD_TOO_LARGE;
-        }
-    }
+    const int rc = hutk_encode_batch(c, text, offsets, 1, ids_out, ids_cap, oo, &st);
     *n_ids = oo[1];
     if (status) *status = st;
     return rc;

@@ -54,6 +54,7 @@ struct ExcRec {
     int64_t ws;        // global byte offset of the word
     int64_t tok_base;  // its ids start at exc_tok[tok_base] (written by the exception kernel;
                        // negative: the word was too large, -(offset in document)-1)
+    int64_t out_pos;   // position of the word's first id in ids_out (written by the gather kernel)
     int32_t len;       // byte length, or -1 when the end lies beyond the staged window
     uint32_t wpos;     // ids the tile emitted before this word (tile-local)
     uint32_t cnt;      // ids of this word (written by the exception kernel)

@@ -637,6 +637,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 ExcRec rec;
                 rec.ws = t0 + ws;
                 rec.tok_base = 0;
+                rec.out_pos = 0;
                 rec.len = known_end ? nb : -1;
                 rec.wpos = pos;
                 rec.cnt = 0;
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspac
         for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = run[k];
         return;
     }
-    const ExcRec* recs = W.exc + W.tile_exc_first[tile];
+    ExcRec* recs = W.exc + W.tile_exc_first[tile];
     for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) e_pos[e] = recs[e].wpos;
     __syncthreads();
     if (tid == 0) {
@@ -997,9 +998,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspac
     }
     for (uint32_t e = 0; e < nexc; e++) {
         const ExcRec r = recs[e];
+        const int64_t dst = base + r.wpos + e_cum[e];
+        if (tid == 0) recs[e].out_pos = dst;
         if (r.tok_base < 0) continue;
         const int32_t* src = W.exc_tok + r.tok_base;
-        const int64_t dst = base + r.wpos + e_cum[e];
         for (uint32_t j = tid; j < r.cnt; j += GATHER_THREADS) A.ids_out[dst + j] = src[j];
     }
 }

@@ -35,7 +35,7 @@ enum {
     HUTK_E_UNSUPPORTED = 6,     /* a file shape the device tables cannot hold */
     HUTK_E_CAPACITY = 7,        /* ids_cap below hutk_ids_capacity() */
     HUTK_E_NUL_BYTE = 8,        /* a 0x00 byte inside a document */
-    HUTK_E_WORD_TOO_LARGE = 9,  /* RuntimeError (core.c:402-407, lib.c:796-808) */
+    HUTK_E_WORD_TOO_LARGE = 9,  /* device-side note only, see HUTK_DOC_WORD_TOO_LARGE */
     HUTK_E_INVALID_UTF8 = 10    /* non-byte-encoder mode only; the reference's
                                    behaviour there is undefined */
 };
@@ -43,8 +43,10 @@ enum {
 /* per-document status values written to status[] */
 enum {
     HUTK_DOC_OK = 0,
-    HUTK_DOC_WORD_TOO_LARGE = 1, /* ids hold the tokens BEFORE the offending word,
-                                    as hutoken.encode() returns them (lib.c:692-697) */
+    HUTK_DOC_WORD_TOO_LARGE = 1, /* a word longer than 262144 bytes (core.c:402-407).  The
+                                    reference reports NOTHING for it (core.c:503 clears the
+                                    message again) and ends the document there; so does
+                                    hutk_encode_batch: the ids are those before that word */
     HUTK_DOC_INVALID_UTF8 = 2
 };
 
@@ -77,9 +79,7 @@ int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs);
  *   out_offsets  int64[n_docs+1]; document i's ids are
  *                ids_out[out_offsets[i] .. out_offsets[i+1])
  *   status       int32[n_docs] (HUTK_DOC_*), may be NULL
- * Returns HUTK_OK, or the first error (HUTK_E_WORD_TOO_LARGE mirrors
- * lib.c:796-808: the reference discards the whole batch; here the outputs stay
- * valid and status[] says which documents were cut). */
+ * Returns HUTK_OK or the first error. */
 int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offsets,
                       int64_t n_docs, int32_t* ids_out, int64_t ids_cap,
                       int64_t* out_offsets, int32_t* status);
@@ -90,7 +90,9 @@ int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offset
  * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and
  * the call returns without synchronising; d_err receives the first device-side
  * error code (HUTK_OK when none) and may be NULL.  d_bytes must be 16-byte
- * aligned. */
+ * aligned.  Unlike hutk_encode_batch this form does not trim a document at an
+ * over-long word: such a document (d_status[i] = HUTK_DOC_WORD_TOO_LARGE, *d_err =
+ * HUTK_E_WORD_TOO_LARGE) holds the ids of all its other words. */
 int hutk_encode_batch_device(hutk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets,
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out,
                              int64_t ids_cap, int64_t* d_out_offsets, int32_t* d_status,

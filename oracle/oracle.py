@@ -150,13 +150,12 @@ class Oracle:
         return ids, out_offs, status[:n]
 
     def batch_encode(self, texts, num_threads=1):
-        """hutoken.batch_encode(): first failing document aborts the batch
-        (lib.c:796-808)."""
+        """hutoken.batch_encode().  An over-long word is NOT reported: core.c:503 resets
+        task->error_msg after the word loop, so lib.c:796-808 never fires and the
+        document simply ends before that word, exactly as in encode()."""
         data, offs = pack(texts)
         ids, oo, status = self.encode_packed(data, offs, num_threads)
         for s in status:
-            if s == DOC_WORD_TOO_LARGE:
-                raise RuntimeError(WORD_TOO_LARGE_MSG)
-            if s != DOC_OK:
+            if s not in (DOC_OK, DOC_WORD_TOO_LARGE):
                 raise RuntimeError(f"oracle document status {s}")
         return [ids[oo[i]:oo[i + 1]].tolist() for i in range(len(texts))]

@@ -1,0 +1,175 @@
+"""GPU path against the committed golden vectors (the reference's own outputs) and, at the
+full BASELINE sizes, size-independent properties.  Needs a real MI355X."""
+import hashlib
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from hutoken_amd import vocab_files as vf
+
+pytestmark = pytest.mark.gpu
+
+
+def sha_ids(list_of_lists):
+    h = hashlib.sha256()
+    for ids in list_of_lists:
+        h.update(np.asarray(ids, dtype="<i4").tobytes())
+        h.update(b"|")
+    return h.hexdigest()
+
+
+def load(name):
+    with open(os.path.join(H.GOLDEN_DIR, name)) as f:
+        return json.load(f)
+
+
+def ctx_for(vp, sp, prefix, is_byte):
+    from hutoken_amd import _capi
+    return _capi.Context(vp, sp, prefix, is_byte)
+
+
+def encode_texts(ctx, texts):
+    from oracle import oracle as O  # only its packer (str -> bytes, cut at NUL)
+    data, offs = O.pack(texts)
+    ids, oo, st, rc = ctx.encode_packed(data, offs)
+    assert rc == 0
+    return [ids[oo[i]:oo[i + 1]].tolist() for i in range(len(texts))]
+
+
+def test_g1_handpicked(tmp_path):
+    g = load("g1_handpicked.json")
+    t = vf.bytes_to_unicode()
+    raw = [bytes([b]) for b in vf.byte_token_order()] + [bytes.fromhex(m) for m in g["byte_vocab"]["merges_hex"]]
+    vp, sp = H.write_vocab(tmp_path, "g1", [(vf.encode_visible(tok, t), i) for i, tok in enumerate(raw)],
+                           vf.gpt2_special_mapping())
+    ctx = ctx_for(vp, sp, None, True)
+    cases = g["byte_vocab"]["cases"]
+    assert encode_texts(ctx, [c["text"] for c in cases]) == [c["ids"] for c in cases]
+    for c in cases[:20]:  # one document per call as well (hutk_encode)
+        assert ctx.encode_one(c["text"].encode("utf-8"))[0] == c["ids"]
+    ents, spm = H.random_char_vocab(5, n_merges=300, drop_chars="qző漢")
+    vp, sp = H.write_vocab(tmp_path, "g1c", ents, spm)
+    ctx = ctx_for(vp, sp, "▁", False)
+    cases = g["char_vocab"]["cases"]
+    assert encode_texts(ctx, [c["text"] for c in cases]) == [c["ids"] for c in cases]
+
+
+def test_g2_mid_vocabs(tmp_path):
+    for g in load("g2_mid_vocabs.json"):
+        ents, sp = H.random_byte_vocab(g["seed"], n_merges=2000, proper=g["proper"], dup_ids=g["dup_ids"])
+        vp, spath = H.write_vocab(tmp_path, "g2_%d" % g["seed"], ents, sp)
+        ctx = ctx_for(vp, spath, None, True)
+        rng = random.Random(g["seed"] * 1000)
+        texts = [H.random_text(rng, max_words=30) for _ in range(1500)]
+        res = encode_texts(ctx, texts)
+        assert res[:40] == g["first"]
+        assert sum(len(x) for x in res) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]
+
+
+@pytest.mark.parametrize("fixture,vocab", [("g3_vg_corpora.json", "VG"), ("g4_vl_corpora.json", "VL")])
+def test_corpora(fixture, vocab):
+    from hutoken_amd import data, synth
+    vp, sp, kw = data.vocab_files(vocab)
+    ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    for g in load(fixture):
+        if "text" in g:
+            assert ctx.encode_one(g["text"].encode())[0] == g["ids"]
+            continue
+        d, o = synth.corpus(g["corpus"], g["n_docs"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == g["corpus_sha256"]
+        ids, oo, st, rc = ctx.encode_packed(d, o)
+        assert rc == 0
+        res = [ids[oo[i]:oo[i + 1]].tolist() for i in range(g["n_docs"])]
+        assert res[:len(g["first"])] == g["first"]
+        assert int(oo[-1]) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]
+
+
+def test_full_size_c2_against_oracle(vg_files, oracle_mod):
+    """BASELINE config 2: 100k docs, mean 256 B ASCII -- every id compared."""
+    from hutoken_amd import synth
+    vp, sp, kw = vg_files
+    ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C2")
+    ids_g, oo_g, st, rc = ctx.encode_packed(d, o)
+    ids_o, oo_o, _ = orc.encode_packed(d, o, os.cpu_count() or 8)
+    assert rc == 0 and np.array_equal(oo_g, oo_o) and np.array_equal(ids_g, ids_o)
+
+
+def test_full_size_c3_properties(vg_files, oracle_mod):
+    """BASELINE config 3: 1M docs, mean 512 B mixed UTF-8.  Checked through properties that do not
+    need the oracle at full size: (1) a batch equals the concatenation of its shards (any cut);
+    (2) reversing the document order permutes the per-document id lists; (3) a seeded sample of
+    documents equals the oracle; (4) documents re-packed with empty documents interleaved."""
+    from hutoken_amd import sharding, synth
+    vp, sp, kw = vg_files
+    ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    n = 1_000_000
+    d, o = synth.corpus("C3", n)
+    ids, oo, st, rc = ctx.encode_packed(d, o)
+    assert rc == 0 and (st == 0).all()
+    # (1) shards
+    parts = sharding.shard_by_bytes(o, 3)
+    cat_ids, bases = [], []
+    for first, count in parts:
+        ld, lo = sharding.local_view(d, o, first, count)
+        i2, o2, _, rc2 = ctx.encode_packed(ld, lo)
+        assert rc2 == 0
+        cat_ids.append(i2)
+        bases.append(int(o2[-1]))
+    assert np.array_equal(np.concatenate(cat_ids), ids)
+    assert sum(bases) == int(oo[-1])
+    # (3) sample vs oracle
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(n, size=3000, replace=False))
+    sd = np.concatenate([d[o[i]:o[i + 1]] for i in pick])
+    so = np.zeros(len(pick) + 1, dtype=np.int64)
+    so[1:] = np.cumsum([o[i + 1] - o[i] for i in pick])
+    ids_o, oo_o, _ = orc.encode_packed(sd, so, 8)
+    for k, i in enumerate(pick):
+        assert np.array_equal(ids[oo[i]:oo[i + 1]], ids_o[oo_o[k]:oo_o[k + 1]]), int(i)
+    # (2) + (4) on a 50k-document slice: reversed order with empty documents interleaved
+    m = 50_000
+    docs = [d[o[i]:o[i + 1]] for i in range(m)]
+    rev = []
+    for x in reversed(docs):
+        rev.append(x)
+        rev.append(d[0:0])
+    rd = np.concatenate(rev)
+    ro = np.zeros(len(rev) + 1, dtype=np.int64)
+    ro[1:] = np.cumsum([len(x) for x in rev])
+    ids_r, oo_r, _, rc3 = ctx.encode_packed(rd, ro)
+    assert rc3 == 0
+    for i in range(0, m, 97):
+        j = 2 * (m - 1 - i)
+        assert np.array_equal(ids_r[oo_r[j]:oo_r[j + 1]], ids[oo[i]:oo[i + 1]])
+        assert oo_r[j + 1] == oo_r[j + 2]  # the interleaved empty document
+
+
+def test_errors_and_limits(tmp_path, oracle_mod):
+    ents, sp = H.random_byte_vocab(4, n_merges=200)
+    vp, spath = H.write_vocab(tmp_path, "e", ents, sp)
+    ctx = ctx_for(vp, spath, None, True)
+    orc = oracle_mod.Oracle(vp, spath, None, True)
+    # a 0x00 byte inside a document is an error of the packed interface
+    with pytest.raises(ValueError, match="0x00"):
+        ctx.encode_packed(np.frombuffer(b"ab\0cd", dtype=np.uint8), np.array([0, 5], dtype=np.int64))
+    # the reference's word limit: 262144 bytes pass, 262145 silently end the document (core.c:402-407, 503)
+    ok = b"hi " + b"x" * 262143 + b" yo"      # " x..." is 262144 bytes with its leading space
+    cut = b"hi " + b"x" * 262144 + b" yo"
+    docs = [b"before", ok, cut, b"after"]
+    from oracle import oracle as O
+    data, offs = O.pack(docs)
+    ids_o, oo_o, st_o = orc.encode_packed(data, offs, 4)
+    ids_g, oo_g, st_g, rc = ctx.encode_packed(data, offs)
+    assert rc == 0
+    assert st_o.tolist() == [0, 0, 1, 0] == st_g.tolist()
+    assert np.array_equal(oo_o, oo_g) and np.array_equal(ids_o, ids_g)
+    assert ids_g[oo_g[2]:oo_g[3]].tolist() == orc.encode(b"hi")

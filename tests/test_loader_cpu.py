@@ -1,0 +1,117 @@
+"""Loader behaviour of the product (host-only context, no GPU) against the reference's
+observable quirks (src/lib.c:243-388, 460-571) and against the oracle's loader."""
+import os
+
+import pytest
+
+import helpers as H
+from hutoken_amd import _capi, vocab_files as vf
+
+
+def host_ctx(vp, sp, prefix=None, is_byte=True):
+    return _capi.Context(vp, sp, prefix, is_byte, device=-2)
+
+
+def write(tmp_path, name, text, mode="w"):
+    p = os.path.join(str(tmp_path), name)
+    with open(p, mode) as f:
+        f.write(text)
+    return p
+
+
+@pytest.fixture()
+def special(tmp_path):
+    p = os.path.join(str(tmp_path), "sp.txt")
+    vf.write_special_file(p, vf.gpt2_special_mapping())
+    return p
+
+
+def both(vp, sp, **kw):
+    """Error class + message from the oracle's loader and from the product's."""
+    from oracle import oracle as O
+    out = []
+    for make in (lambda: O.Oracle(vp, sp, kw.get("prefix"), kw.get("is_byte", True)),
+                 lambda: host_ctx(vp, sp, kw.get("prefix"), kw.get("is_byte", True))):
+        try:
+            make()
+            out.append(None)
+        except Exception as e:  # noqa: BLE001
+            out.append((type(e), str(e)))
+    return out
+
+
+def test_invalid_format_message(tmp_path, special):
+    vp = write(tmp_path, "v.txt", "invalid_line_format\n")
+    a, b = both(vp, special)
+    assert a == b == (ValueError, "Invalid format in vocab file.")  # reference tests/test_tokenizer.py:137-141
+
+
+def test_error_messages_match(tmp_path, special):
+    cases = {
+        "0x61 == x\n": (ValueError, "Invalid vocab format: could not parse integer value."),
+        "0x61 == 99999999999999999999\n": (ValueError, "Integer value in vocab file is out of range."),
+        " == 5\n": (ValueError, "Failed to convert hex string to ASCII."),
+        "0x00 == 5\n": (ValueError, "Failed to convert hex string to ASCII."),
+        "": (ValueError, "Vocab file is empty."),
+        "0x61 == 1": (ValueError, "Vocab file is empty."),  # the only line lacks its newline: dropped
+    }
+    for text, want in cases.items():
+        vp = write(tmp_path, "v.txt", text)
+        a, b = both(vp, special)
+        assert a == b == want, repr(text)
+    a, b = both(os.path.join(str(tmp_path), "missing.txt"), special)
+    assert a == b == (FileNotFoundError, "Could not open vocab file.")
+    vp = write(tmp_path, "v.txt", "0x61 == 0\n")
+    a, b = both(vp, os.path.join(str(tmp_path), "nosuch.txt"))
+    assert a == b == (FileNotFoundError, "Could not open special characters file.")
+
+
+def test_special_file_errors(tmp_path):
+    vp = write(tmp_path, "v.txt", "0x61 == 0\n")
+    cases = {
+        "nonsense\n": (ValueError, "Invalid format in special character file."),
+        "x == y\n": (ValueError, "Invalid vocab format: could not parse integer value."),
+        "256 == y\n": (ValueError, "Integer value in vocab file is out of range."),  # reference: out of bounds write
+        "-1 == y\n": (ValueError, "Integer value in vocab file is out of range."),
+        "5 == \n": (ValueError, "Failed to convert hex string to ASCII."),
+        "5 == aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa\n": (ValueError, "Invalid format in special character file."),
+    }
+    for text, want in cases.items():
+        sp = write(tmp_path, "s.txt", text)
+        a, b = both(vp, sp)
+        assert a == b == want, repr(text)
+
+
+def test_quirks_last_line_duplicates_truncation(tmp_path, special, oracle_mod):
+    # unterminated final line dropped; a repeated key keeps its LAST id; a key ends at 0x00;
+    # "0X" is not a hex marker; non-hex characters are skipped
+    text = "0x61 == 0\n0x62 == 1\n0x61 == 7\n0x630x000x64 == 2\n0x65zz0x66 == 3\n0x67 == 9"
+    vp = write(tmp_path, "v.txt", text)
+    orc = oracle_mod.Oracle(vp, special, None, True)
+    assert orc.vocab_count == 4
+    assert orc.lookup(b"a") == 7 and orc.lookup(b"b") == 1 and orc.lookup(b"c") == 2
+    assert orc.lookup(b"ef") == 3 and orc.lookup(b"g") is None
+    st = host_ctx(vp, special).table_stats()
+    assert st["n_keys"] == 4
+
+
+def test_table_shapes(vg_files, vl_files):
+    vp, sp, kw = vg_files
+    st = host_ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]).table_stats()
+    assert st["n_keys"] == 50257 and st["n_vocab_sym"] == 50257
+    assert st["rank_is_sym"] == 1 and st["ident_ids"] == 1
+    assert st["n_pairs"] > 50000 and st["pair_slots"] >= 2 * st["n_pairs"]
+    vp, sp, kw = vl_files
+    st = host_ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]).table_stats()
+    assert st["n_keys"] == 32000 and st["n_sym"] >= 32000
+
+
+def test_unsupported_special_files_are_rejected_loudly(tmp_path):
+    vp = write(tmp_path, "v.txt", "0x61 == 0\n")
+    for text in (b"97 == Alpha\n",      # more than one unit per replacement
+                 b"97 == <0x4\n",       # ends inside a "<0x..>" literal: the split would depend on the next item
+                 b"97 == 0x41>\n",      # could complete a literal begun by a raw '<'
+                 b"97 == \xc3\n"):      # truncated UTF-8 sequence
+        sp = write(tmp_path, "s.txt", text, mode="wb")
+        with pytest.raises(ValueError):
+            host_ctx(vp, sp)

@@ -1,0 +1,56 @@
+"""Python surface of the drop-in module: signatures, exception classes and the messages the
+reference pins (reference hutoken.py:22-43, 122-139; tests/test_tokenizer.py:43-46, 137-141)."""
+import importlib
+import inspect
+import os
+
+import pytest
+
+import helpers as H
+
+
+@pytest.fixture()
+def hutoken():
+    import hutoken_amd
+    m = importlib.reload(hutoken_amd)  # fresh, uninitialised module state
+    return m
+
+
+def test_signatures(hutoken):
+    assert list(inspect.signature(hutoken.encode).parameters) == ["text"]
+    sig = inspect.signature(hutoken.batch_encode)
+    assert list(sig.parameters) == ["texts", "num_threads"] and sig.parameters["num_threads"].default == 1
+    sig = inspect.signature(hutoken.initialize)
+    assert list(sig.parameters) == ["model_or_path", "args", "kwargs"]
+
+
+def test_encode_before_initialize(hutoken):
+    msg = "Vocabulary is not initialized for encoding. Call 'initialize_encode' function first."
+    with pytest.raises(RuntimeError, match=msg):
+        hutoken.encode("szia")
+    with pytest.raises(RuntimeError, match=msg):
+        hutoken.batch_encode(["szia"])
+
+
+def test_initialize_errors(hutoken, tmp_path):
+    vp = os.path.join(str(tmp_path), "v.txt")
+    open(vp, "w").write("invalid_line_format\n")
+    sp = os.path.join(str(tmp_path), "s.txt")
+    open(sp, "w").write("32 == x\n")
+    with pytest.raises(ValueError, match="Invalid format in vocab file."):
+        hutoken.initialize(vp, sp)
+    with pytest.raises(ValueError, match="does not exist"):
+        hutoken.initialize(vp, os.path.join(str(tmp_path), "missing.txt"))
+    with pytest.raises(TypeError, match="Invalid arguments. Expected a string"):
+        hutoken.initialize(vp)  # special file is a required str (lib.c:203 "ss|zpizz")
+    with pytest.raises(ValueError, match="Could not download Hugging Face tokenizer"):
+        hutoken.initialize("NYTK/PULI-LlumiX-32K")
+
+
+def test_out_of_path_features_fail_loudly(hutoken, tmp_path):
+    ents, sp = H.random_byte_vocab(1, n_merges=20)
+    vp, spath = H.write_vocab(tmp_path, "v", ents, sp)
+    with pytest.raises(RuntimeError, match="pattern"):
+        hutoken.initialize(vp, spath, pattern="[a-z]+")
+    with pytest.raises(RuntimeError):
+        hutoken.decode([1, 2, 3])
