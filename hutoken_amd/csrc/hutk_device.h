@@ -73,6 +73,7 @@ struct Workspace {
     uint32_t* tile_nexc;       // [n_tiles]
     int64_t* tile_first_doc;   // [n_tiles] first document whose offset is >= tile start - LOOKBACK
     int64_t* tile_base;        // [n_tiles + 1] exclusive scan of tile_count
+    int64_t* scan_part;        // [n_tiles / 2048 + 1] block totals / bases of that scan
     uint32_t* doc_tile_pos;    // [n_docs + 1] ids the owning tile emits before the document start
     ExcRec* exc;               // [cap_exc]
     uint32_t* counters;        // [0] exception total, [1] exception work cursor

@@ -28,7 +28,7 @@
 //   k_exc      one wavefront per exception word, work pulled from a device counter:
 //              the same merge rule, cooperatively (parallel min over the pair array,
 //              __shfl_xor reduction), arrays in LDS up to 1024 units, else in HBM.
-//   k_scan     exclusive scan of per-tile id counts
+//   k_scan_*   exclusive scan of per-tile id counts (block sums, scan of sums, apply)
 //   k_gather   tile runs (+ exception words) -> caller's ids array
 //   k_doc_off  out_offsets[]
 //
@@ -926,30 +926,72 @@ __global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, const uint32_t*
 }
 
 // ------------------------------------------------------------------------
-// k_scan: exclusive scan of tile_count -> tile_base (one workgroup)
+// exclusive scan of tile_count -> tile_base in three small launches:
+//   k_scan_sums   one workgroup per 2048 tiles: its total            -> scan_part[b]
+//   k_scan_parts  one workgroup: exclusive scan of the block totals  -> scan_part[b], grand total
+//   k_scan_apply  one workgroup per 2048 tiles: local exclusive scan + block base -> tile_base
 // ------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(BatchArgs A, Workspace W) {
-    __shared__ int64_t part[1024];
-    const int tid = threadIdx.x;
-    const int64_t chunk = (A.n_tiles + 1023) / 1024;
-    const int64_t a = tid * chunk < A.n_tiles ? tid * chunk : A.n_tiles;
-    const int64_t b = a + chunk < A.n_tiles ? a + chunk : A.n_tiles;
-    int64_t sum = 0;
-    for (int64_t t = a; t < b; t++) sum += W.tile_count[t];
-    part[tid] = sum;
+constexpr int SCAN_BLOCK = 2048, SCAN_THREADS = 256, SCAN_PER_THREAD = SCAN_BLOCK / SCAN_THREADS;
+
+__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* sh, int tid, int n, int64_t* total) {
+    sh[tid] = v;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int64_t v = tid >= off ? part[tid - off] : 0;
+    for (int off = 1; off < n; off <<= 1) {
+        const int64_t o = tid >= off ? sh[tid - off] : 0;
         __syncthreads();
-        part[tid] += v;
+        sh[tid] += o;
         __syncthreads();
     }
-    int64_t run = part[tid] - sum;
-    for (int64_t t = a; t < b; t++) {
-        W.tile_base[t] = run;
-        run += W.tile_count[t];
+    *total = sh[n - 1];
+    return sh[tid] - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(BatchArgs A, Workspace W) {
+    __shared__ int64_t sh[SCAN_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
+    int64_t sum = 0;
+    for (int k = 0; k < SCAN_PER_THREAD; k++)
+        if (base + k < A.n_tiles) sum += W.tile_count[base + k];
+    int64_t total;
+    (void)block_excl_scan(sum, sh, tid, SCAN_THREADS, &total);
+    if (tid == 0) W.scan_part[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_parts(BatchArgs A, Workspace W, int64_t n_blocks) {
+    __shared__ int64_t sh[1024];
+    const int tid = threadIdx.x;
+    const int64_t chunk = (n_blocks + 1023) / 1024;
+    const int64_t a = tid * chunk < n_blocks ? tid * chunk : n_blocks;
+    const int64_t b = a + chunk < n_blocks ? a + chunk : n_blocks;
+    int64_t sum = 0;
+    for (int64_t i = a; i < b; i++) sum += W.scan_part[i];
+    int64_t total;
+    int64_t run = block_excl_scan(sum, sh, tid, 1024, &total);
+    for (int64_t i = a; i < b; i++) {
+        const int64_t v = W.scan_part[i];
+        W.scan_part[i] = run;
+        run += v;
     }
-    if (tid == 1023) W.tile_base[A.n_tiles] = part[1023];
+    if (tid == 0) W.tile_base[A.n_tiles] = total;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(BatchArgs A, Workspace W) {
+    __shared__ int64_t sh[SCAN_THREADS];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
+    uint32_t c[SCAN_PER_THREAD];
+    int64_t sum = 0;
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        c[k] = (base + k < A.n_tiles) ? W.tile_count[base + k] : 0u;
+        sum += c[k];
+    }
+    int64_t total;
+    int64_t run = W.scan_part[blockIdx.x] + block_excl_scan(sum, sh, tid, SCAN_THREADS, &total);
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        if (base + k < A.n_tiles) W.tile_base[base + k] = run;
+        run += c[k];
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -1056,7 +1098,10 @@ void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& 
     hipLaunchKernelGGL(k_exc, dim3(4096), dim3(64), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, a, w);
+    const int64_t nb = (a.n_tiles + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
+    hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(1024), 0, s, a, w, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
 }
 void launch_gather(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(GATHER_THREADS), 0, s, a, w);
