@@ -247,16 +247,21 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ uint32_t docm[WINDOW / 32 + 3];
     __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
     __shared__ __attribute__((aligned(8))) uint16_t rmask16[64 + 8];  // pair (r, r+1) has a rank
-    __shared__ uint32_t lanepref[64];                                  // ids before lane l's positions
-    __shared__ uint16_t order[TILE_BYTES];                              // lane words, longest first: ws | n << 10
-    __shared__ uint16_t wlist[TILE_BYTES];                              // word starts of the tile, in order
+    __shared__ uint16_t wlist[TILE_BYTES];                              // word starts of the tile, in order (| n << 10)
     __shared__ uint32_t missbits[(TILE_BYTES + 31) / 32];               // word index -> goes to the merge loop
     __shared__ __attribute__((aligned(16))) SymT S[NPOS];
     __shared__ __attribute__((aligned(16))) SymT M[NPOS];
     __shared__ SymT s_item_sym[256];
-    __shared__ uint8_t s_item_direct[256];
+    __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     __shared__ uint32_t hist[64], hbase[64];
     __shared__ uint32_t s_next;
+    // LDS is what limits resident wavefronts here, so two arrays live in dead storage:
+    //   order (lane words, longest first: ws | n << 10) over the staged bytes, which nobody reads
+    //         once the words are classified (one-unit words never enter it)
+    //   lanepref (ids before lane l's positions) over the histogram, dead after the bucketing
+    uint16_t* const order = reinterpret_cast<uint16_t*>(sb);
+    constexpr int ORDER_CAP = WINDOW / 2;  // 528 >= 480 = the most multi-unit words 960 bytes can start
+    uint32_t* const lanepref = hist;
 
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     }
     for (int i = lane; i < 256; i += 64) {
         s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
-        s_item_direct[i] = T.item_direct[i];
+        if (!BYTE_MODE) s_item_direct[i] = T.item_direct[i];
     }
     if (lane < WINDOW / 32 + 3) docm[lane] = 0;
     hist[lane] = 0;
@@ -411,7 +416,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             M[ws] = (SymT)EXC_MARK;
             continue;
         }
-        if (BYTE_MODE && T.word_mask && nb <= 16 && nb > 1) {
+        if (n == 1) {  // a single unit: nothing to merge, its symbol already sits in S[ws]
+            M[ws] = (SymT)1;
+            continue;
+        }
+        if (BYTE_MODE && T.word_mask && nb <= 16) {
             // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
             // token it encodes to.  Entries were verified by this pipeline at context creation.
             const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         }
         atomicAdd(&hist[n], 1u);
         atomicOr(&missbits[wi >> 5], 1u << (wi & 31));
+        wlist[wi] = (uint16_t)(ws | (n << 10));
     }
     __syncthreads();
     {  // longest first: bucket n starts after all longer buckets
@@ -455,21 +465,19 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         hbase[lane] = acc;
     }
     __syncthreads();
-    const int nL = (int)(hbase[0] + hist[0]);
+    const int nL_all = (int)(hbase[0] + hist[0]);
+    const int nL = nL_all < ORDER_CAP ? nL_all : ORDER_CAP;
     __syncthreads();
     hist[lane] = 0;
     if (lane == 0) s_next = 64;
     __syncthreads();
     for (uint32_t wi = lane; wi < nW; wi += 64) {
         if (!((missbits[wi >> 5] >> (wi & 31)) & 1u)) continue;
-        const int ws = wlist[wi];
-        const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
-        int n = nb;
-        if (!BYTE_MODE) {  // units = characters = lead bytes
-            n = 0;
-            for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
-        }
-        order[hbase[n] + atomicAdd(&hist[n], 1u)] = (uint16_t)(ws | (n << 10));
+        const uint32_t e = wlist[wi];
+        const uint32_t n = e >> 10;
+        const uint32_t slot = hbase[n] + atomicAdd(&hist[n], 1u);
+        if (slot < (uint32_t)ORDER_CAP) order[slot] = (uint16_t)e;
+        else M[e & 1023u] = (SymT)EXC_MARK;  // more multi-token words than the list holds: exception path
     }
     __syncthreads();
     HUTK_STAMP(4);

@@ -121,6 +121,16 @@ def test_long_words_exception_path(small_byte):
         _compare(ctx, orc, docs, "long")
 
 
+def test_dense_word_tiles(small_byte):
+    """Tiles packed with the shortest possible words: every byte a word (newlines, stray bytes), and
+    two-byte words back to back (the most multi-unit words a tile can start)."""
+    docs = [b"\n" * 5000, b"\xff\x80" * 3000, b"a " * 4000, b" a" * 4000, b"ab" + b"\tab" * 3000,
+            b"a1" * 3000, b".a" * 3000 + b"!" * 2000, bytes(range(1, 256)) * 20]
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, docs, "dense")
+        _compare(ctx, orc, [bytes([b]) for b in range(1, 256)] * 8, "one-byte-docs")
+
+
 def test_random_text_char_mode_with_prefix(small_char):
     for k, (ctx, orc) in enumerate(small_char):
         rng = random.Random(300 + k)
