@@ -367,8 +367,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
     }
     uint32_t nW;
+    const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
     {
-        uint32_t at = wave_excl_scan(__popc(own), lane, &nW);
+        uint32_t at = wbase;
         for (uint32_t m = own; m; m &= m - 1) wlist[at++] = (uint16_t)(16 * lane + __builtin_ctz(m));
     }
     if (lane < (TILE_BYTES + 31) / 32) missbits[lane] = 0;
@@ -442,14 +443,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             else { k3 &= keep; }
             uint32_t h = word_hash(k0, k1, k2, k3) & T.word_mask;
             bool hit = false;
+            uint32_t hsym = 0;
             for (;;) {
                 const uint4 key = T.word_keys[h];
+                hsym = T.word_syms[h];  // issued with the key: one latency, not two
                 if (key.x == k0 && key.y == k1 && key.z == k2 && key.w == k3) { hit = true; break; }
                 if (key.x == 0) break;
                 h = (h + 1) & T.word_mask;
             }
             if (hit) {
-                S[ws] = Sym<SymT>::narrow(T.word_syms[h]);
+                S[ws] = Sym<SymT>::narrow(hsym);
                 M[ws] = (SymT)1;
                 continue;
             }
@@ -459,10 +462,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         wlist[wi] = (uint16_t)(ws | (n << 10));
     }
     __syncthreads();
-    {  // longest first: bucket n starts after all longer buckets
-        uint32_t acc = 0;
-        for (int m = 63; m > lane; m--) acc += hist[m];
-        hbase[lane] = acc;
+    {  // longest first: bucket n starts after all longer buckets (suffix sums by lane shuffles)
+        const uint32_t mine_h = hist[lane];
+        uint32_t inc = mine_h;  // inclusive suffix sum over lanes >= this one
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_down(inc, off, 64);
+            if (lane + off < 64) inc += o;
+        }
+        hbase[lane] = inc - mine_h;
     }
     __syncthreads();
     const int nL_all = (int)(hbase[0] + hist[0]);
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         const uint32_t n = e >> 10;
         const uint32_t slot = hbase[n] + atomicAdd(&hist[n], 1u);
         if (slot < (uint32_t)ORDER_CAP) order[slot] = (uint16_t)e;
-        else M[e & 1023u] = (SymT)EXC_MARK;  // more multi-token words than the list holds: exception path
+        else raise(A.err, HUTK_E_MEMORY);  // cannot happen: at most 480 multi-unit words start in 960 bytes
     }
     __syncthreads();
     HUTK_STAMP(4);
@@ -499,9 +506,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             // finish exhausted words and fetch until this lane holds a word with work
             while ((have && cand == 0) || (!have && k < nL)) {
                 if (have) {
-                    int cnt = 0;
-                    for (uint32_t c = live; c; c &= c - 1) S[ws + cnt++] = S[ws + __builtin_ctz(c)];
-                    M[ws] = (SymT)cnt;
+                    // done: park the mask of surviving units (n >= 2 here, so M[ws + 1] is this word's own)
+                    M[ws] = (SymT)(live & 0xFFFFu);
+                    M[ws + 1] = (SymT)(live >> 16);
                     have = false;
                     k = (int)atomicAdd(&s_next, 1u);
                 }
@@ -607,14 +614,29 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     HUTK_STAMP(5);
 
     // ---- 7. per-position epilogue: counts -> scan -> ids out, exception records ----
+    // M[word start] now holds: EXC_MARK (exception word), 1 (single unit / whole-word hit), or -- for the
+    // words of the merge loop (missbits) -- the low half of the survivor mask (high half in the next slot)
+    auto survivors = [&](int ws, uint32_t wi, bool* is_exc) -> uint32_t {
+        const uint32_t lo = M[ws];
+        if ((missbits[wi >> 5] >> (wi & 31)) & 1u) {
+            *is_exc = false;
+            return lo | ((uint32_t)M[ws + 1] << 16);
+        }
+        *is_exc = lo == EXC_MARK;
+        return *is_exc ? 0u : 1u;
+    };
     uint32_t mine = 0;  // low 16: ids, high 16: exception words
-    for (uint32_t m = own; m; m &= m - 1) {
-        const uint32_t c = M[16 * lane + __builtin_ctz(m)];
-        mine += (c == EXC_MARK) ? 0x10000u : c;
+    {
+        uint32_t wi = wbase;
+        for (uint32_t m = own; m; m &= m - 1, wi++) {
+            bool is_exc;
+            const uint32_t sv = survivors(16 * lane + __builtin_ctz(m), wi, &is_exc);
+            mine += is_exc ? 0x10000u : (uint32_t)__popc(sv);
+        }
     }
     uint32_t total;
     uint32_t run = wave_excl_scan(mine, lane, &total);
-    lanepref[lane] = run & 0xFFFFu;
+    lanepref[lane] = (run & 0xFFFFu) | (wbase << 16);  // ids before this lane's words | index of its first word
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
     const unsigned long long has_words = __ballot(own != 0);
     const int first_lane = has_words ? __builtin_ctzll(has_words) : 0;
@@ -632,32 +654,37 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
     int32_t* run_out = W.run + t0 + run_start;
-    for (uint32_t m = own; m; m &= m - 1) {
-        const int ws = 16 * lane + __builtin_ctz(m);
-        const uint32_t c = M[ws];
-        const uint32_t pos = run & 0xFFFFu;
-        if (c == EXC_MARK) {
-            const uint64_t slot = (uint64_t)exc_first + (run >> 16);
-            if ((int64_t)slot < W.cap_exc) {
-                const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-                const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-                const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
-                ExcRec rec;
-                rec.ws = t0 + ws;
-                rec.tok_base = 0;
-                rec.out_pos = 0;
-                rec.len = known_end ? nb : -1;
-                rec.wpos = pos;
-                rec.cnt = 0;
-                rec.tile = (uint32_t)tile;
-                W.exc[slot] = rec;
+    {
+        uint32_t wi = wbase;
+        for (uint32_t m = own; m; m &= m - 1, wi++) {
+            const int ws = 16 * lane + __builtin_ctz(m);
+            bool is_exc;
+            uint32_t sv = survivors(ws, wi, &is_exc);
+            uint32_t pos = run & 0xFFFFu;
+            if (is_exc) {
+                const uint64_t slot = (uint64_t)exc_first + (run >> 16);
+                if ((int64_t)slot < W.cap_exc) {
+                    const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+                    const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                    const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                    ExcRec rec;
+                    rec.ws = t0 + ws;
+                    rec.tok_base = 0;
+                    rec.out_pos = 0;
+                    rec.len = known_end ? nb : -1;
+                    rec.wpos = pos;
+                    rec.cnt = 0;
+                    rec.tile = (uint32_t)tile;
+                    W.exc[slot] = rec;
+                } else {
+                    raise(A.err, HUTK_E_MEMORY);
+                }
+                run += 0x10000u;
             } else {
-                raise(A.err, HUTK_E_MEMORY);
+                run += (uint32_t)__popc(sv);
+                for (; sv; sv &= sv - 1)  // surviving units, left to right
+                    run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(S[ws + __builtin_ctz(sv)]));
             }
-            run += 0x10000u;
-        } else {
-            for (uint32_t j = 0; j < c; j++) run_out[pos + j] = sym_to_id(T, Sym<SymT>::widen(S[ws + j]));
-            run += c;
         }
     }
     __syncthreads();
@@ -670,11 +697,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (o < t0) continue;
         const int r = (int)(o - t0);
         const int lr = r >> 4;
-        uint32_t before = lanepref[lr];
+        uint32_t before = lanepref[lr] & 0xFFFFu;
+        uint32_t wi = lanepref[lr] >> 16;
         uint32_t fl = wmask16[lr] & ((1u << (r & 15)) - 1u);
-        for (; fl; fl &= fl - 1) {
-            const uint32_t c = M[16 * lr + __builtin_ctz(fl)];
-            if (c != EXC_MARK) before += c;
+        for (; fl; fl &= fl - 1, wi++) {
+            bool is_exc;
+            before += (uint32_t)__popc(survivors(16 * lr + __builtin_ctz(fl), wi, &is_exc));
         }
         W.doc_tile_pos[d] = before;
     }
