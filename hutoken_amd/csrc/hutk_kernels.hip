@@ -247,21 +247,13 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ uint32_t docm[WINDOW / 32 + 3];
     __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
     __shared__ __attribute__((aligned(8))) uint16_t rmask16[64 + 8];  // pair (r, r+1) has a rank
-    __shared__ uint16_t wlist[TILE_BYTES];                              // word starts of the tile, in order (| n << 10)
-    __shared__ uint32_t missbits[(TILE_BYTES + 31) / 32];               // word index -> goes to the merge loop
+    __shared__ __attribute__((aligned(8))) uint32_t mergem[NPOS / 32 + 2];  // positions whose word needs the merge loop
+    __shared__ uint16_t stage[64];                                      // word starts handed to the lanes, 64 at a time
     __shared__ __attribute__((aligned(16))) SymT S[NPOS];
     __shared__ __attribute__((aligned(16))) SymT M[NPOS];
     __shared__ SymT s_item_sym[256];
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
-    __shared__ uint32_t hist[64], hbase[64];
-    __shared__ uint32_t s_next;
-    // LDS is what limits resident wavefronts here, so two arrays live in dead storage:
-    //   order (lane words, longest first: ws | n << 10) over the staged bytes, which nobody reads
-    //         once the words are classified (one-unit words never enter it)
-    //   lanepref (ids before lane l's positions) over the histogram, dead after the bucketing
-    uint16_t* const order = reinterpret_cast<uint16_t*>(sb);
-    constexpr int ORDER_CAP = WINDOW / 2;  // 528 >= 480 = the most multi-unit words 960 bytes can start
-    uint32_t* const lanepref = hist;
+    __shared__ uint16_t lanepref[64];  // ids before lane l's positions
 
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -292,7 +284,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (!BYTE_MODE) s_item_direct[i] = T.item_direct[i];
     }
     if (lane < WINDOW / 32 + 3) docm[lane] = 0;
-    hist[lane] = 0;
+    if (lane < NPOS / 32 + 2) mergem[lane] = 0;
     if (lane < 8) { wmask16[64 + lane] = 0xFFFFu; rmask16[64 + lane] = 0; }
     __syncthreads();
 
@@ -358,7 +350,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __syncthreads();
     HUTK_STAMP(3);
 
-    // ---- 5. word list; whole-word table; bucket the remaining words by unit count ----
+    // ---- 5. words, spread evenly over the lanes: whole-word table; mark what needs merging ----
+    // Word j of the tile goes to lane j % 64: every round the owning lanes put the starts of words
+    // [r0, r0 + 64) into a 64-entry staging buffer (no per-tile word list is kept in LDS: its
+    // footprint would cost resident wavefronts, and residency is what hides the gather latency).
     const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
     uint32_t own = flags;                    // starts that are words of this tile
     {
@@ -368,257 +363,234 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     }
     uint32_t nW;
     const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
-    {
-        uint32_t at = wbase;
-        for (uint32_t m = own; m; m &= m - 1) wlist[at++] = (uint16_t)(16 * lane + __builtin_ctz(m));
-    }
-    if (lane < (TILE_BYTES + 31) / 32) missbits[lane] = 0;
-    __syncthreads();
-    for (uint32_t wi = lane; wi < nW; wi += 64) {
-        const int ws = wlist[wi];
-        // end of the word: the next start bit within 63 positions (bits beyond the
-        // window are ones, which is only true when the data ends there)
-        const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-        const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-        const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
-        const bool docfirst = bit_at(docm, ws + LOOKBACK);
-        bool exc = !known_end || nb > LANE_MAX_BYTES || (T.has_prefix && docfirst);
-        int n = 0;
-        if (!exc) {
-            if (BYTE_MODE) {
-                n = nb;
-            } else {
-                const int lw = ws + LOOKBACK;
-                int i = 0;
-                while (i < nb) {
-                    const uint32_t b = sb[lw + i];
-                    int L = 1;
-                    if (b >= 0x80u) {
-                        L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
-                        if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
+    for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
+        {
+            uint32_t wi = wbase - r0;
+            for (uint32_t m = own; m; m &= m - 1, wi++)
+                if (wi < 64u) stage[wi] = (uint16_t)(16 * lane + __builtin_ctz(m));
+        }
+        __syncthreads();
+        if (r0 + lane < nW) {
+            const int ws = stage[lane];
+            // end of the word: the next start bit within 63 positions (bits beyond the
+            // window are ones, which is only true when the data ends there)
+            const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+            const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+            const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+            const bool docfirst = bit_at(docm, ws + LOOKBACK);
+            bool exc = !known_end || nb > LANE_MAX_BYTES || (T.has_prefix && docfirst);
+            int n = 0;
+            if (!exc) {
+                if (BYTE_MODE) {
+                    n = nb;
+                } else {
+                    const int lw = ws + LOOKBACK;
+                    int i = 0;
+                    while (i < nb) {
+                        const uint32_t b = sb[lw + i];
+                        int L = 1;
+                        if (b >= 0x80u) {
+                            L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                            if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
+                        }
+                        uint32_t sym;
+                        if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
+                        else if (L == 1) sym = SYM_UNK;
+                        else {
+                            uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
+                            if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
+                            if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
+                            sym = char_lookup(T, packed);
+                        }
+                        if (n < LANE_MAX_UNITS) S[ws + n] = Sym<SymT>::narrow(sym);
+                        n++;
+                        i += L;
                     }
-                    uint32_t sym;
-                    if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
-                    else if (L == 1) sym = SYM_UNK;
-                    else {
-                        uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
-                        if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
-                        if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
-                        sym = char_lookup(T, packed);
-                    }
-                    if (n < LANE_MAX_UNITS) S[ws + n] = Sym<SymT>::narrow(sym);
-                    n++;
-                    i += L;
+                }
+                if (n > LANE_MAX_UNITS) exc = true;
+            }
+            bool done = false;
+            if (exc) {
+                M[ws] = (SymT)EXC_MARK;
+                done = true;
+            } else if (n == 1) {  // a single unit: nothing to merge, its symbol already sits in S[ws]
+                M[ws] = (SymT)1;
+                done = true;
+            } else if (BYTE_MODE && T.word_mask && nb <= 16) {
+                // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
+                // token it encodes to.  Entries were verified by this pipeline at context creation.
+                const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
+                const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
+                const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
+                uint32_t k0 = q0, k1 = q1, k2 = q2, k3 = q3;
+                if (o8) {
+                    k0 = funnel_r(q1, q0, o8);
+                    k1 = funnel_r(q2, q1, o8);
+                    k2 = funnel_r(q3, q2, o8);
+                    k3 = funnel_r(q4, q3, o8);
+                }
+                // zero the bytes at and beyond nb
+                const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
+                const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
+                if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
+                else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
+                else if (full == 2) { k2 &= keep; k3 = 0; }
+                else { k3 &= keep; }
+                uint32_t h = word_hash(k0, k1, k2, k3) & T.word_mask;
+                uint32_t hsym = 0;
+                for (;;) {
+                    const uint4 key = T.word_keys[h];
+                    hsym = T.word_syms[h];  // issued with the key: one latency, not two
+                    if (key.x == k0 && key.y == k1 && key.z == k2 && key.w == k3) { done = true; break; }
+                    if (key.x == 0) break;
+                    h = (h + 1) & T.word_mask;
+                }
+                if (done) {
+                    S[ws] = Sym<SymT>::narrow(hsym);
+                    M[ws] = (SymT)1;
                 }
             }
-            if (n > LANE_MAX_UNITS) exc = true;
+            if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
         }
-        if (exc) {
-            M[ws] = (SymT)EXC_MARK;
-            continue;
-        }
-        if (n == 1) {  // a single unit: nothing to merge, its symbol already sits in S[ws]
-            M[ws] = (SymT)1;
-            continue;
-        }
-        if (BYTE_MODE && T.word_mask && nb <= 16) {
-            // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
-            // token it encodes to.  Entries were verified by this pipeline at context creation.
-            const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
-            const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
-            const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
-            uint32_t k0 = q0, k1 = q1, k2 = q2, k3 = q3;
-            if (o8) {
-                k0 = funnel_r(q1, q0, o8);
-                k1 = funnel_r(q2, q1, o8);
-                k2 = funnel_r(q3, q2, o8);
-                k3 = funnel_r(q4, q3, o8);
-            }
-            // zero the bytes at and beyond nb
-            const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
-            const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
-            if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
-            else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
-            else if (full == 2) { k2 &= keep; k3 = 0; }
-            else { k3 &= keep; }
-            uint32_t h = word_hash(k0, k1, k2, k3) & T.word_mask;
-            bool hit = false;
-            uint32_t hsym = 0;
-            for (;;) {
-                const uint4 key = T.word_keys[h];
-                hsym = T.word_syms[h];  // issued with the key: one latency, not two
-                if (key.x == k0 && key.y == k1 && key.z == k2 && key.w == k3) { hit = true; break; }
-                if (key.x == 0) break;
-                h = (h + 1) & T.word_mask;
-            }
-            if (hit) {
-                S[ws] = Sym<SymT>::narrow(hsym);
-                M[ws] = (SymT)1;
-                continue;
-            }
-        }
-        atomicAdd(&hist[n], 1u);
-        atomicOr(&missbits[wi >> 5], 1u << (wi & 31));
-        wlist[wi] = (uint16_t)(ws | (n << 10));
+        __syncthreads();
     }
-    __syncthreads();
-    {  // longest first: bucket n starts after all longer buckets (suffix sums by lane shuffles)
-        const uint32_t mine_h = hist[lane];
-        uint32_t inc = mine_h;  // inclusive suffix sum over lanes >= this one
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_down(inc, off, 64);
-            if (lane + off < 64) inc += o;
-        }
-        hbase[lane] = inc - mine_h;
-    }
-    __syncthreads();
-    const int nL_all = (int)(hbase[0] + hist[0]);
-    const int nL = nL_all < ORDER_CAP ? nL_all : ORDER_CAP;
-    __syncthreads();
-    hist[lane] = 0;
-    if (lane == 0) s_next = 64;
-    __syncthreads();
-    for (uint32_t wi = lane; wi < nW; wi += 64) {
-        if (!((missbits[wi >> 5] >> (wi & 31)) & 1u)) continue;
-        const uint32_t e = wlist[wi];
-        const uint32_t n = e >> 10;
-        const uint32_t slot = hbase[n] + atomicAdd(&hist[n], 1u);
-        if (slot < (uint32_t)ORDER_CAP) order[slot] = (uint16_t)e;
-        else raise(A.err, HUTK_E_MEMORY);  // cannot happen: at most 480 multi-unit words start in 960 bytes
-    }
-    __syncthreads();
     HUTK_STAMP(4);
 
-    // ---- 6. merge: persistent lanes pull words, one merge step per trip ------------
+    // ---- 6. merge: ONE LANE PER WORD, one merge step per trip ------------------------
     // Each lane keeps (br, bp, bm) = rank, position and merged symbol of its word's best pair.
     // A step applies that merge, ISSUES the two pair-table loads for the new neighbour pairs,
     // rescans the untouched candidates in LDS while those loads are in flight, and then
     // picks the next best among {rescan, new left pair, new right pair}.
     {
-        int k = lane;
-        bool have = false;
-        int ws = 0;
-        uint32_t live = 0, cand = 0;  // lane words have at most 32 units
-        uint32_t br = 0xFFFFFFFFu;
-        int bp = 0;
-        SymT bm = 0;
-        for (;;) {
-            // finish exhausted words and fetch until this lane holds a word with work
-            while ((have && cand == 0) || (!have && k < nL)) {
-                if (have) {
-                    // done: park the mask of surviving units (n >= 2 here, so M[ws + 1] is this word's own)
-                    M[ws] = (SymT)(live & 0xFFFFu);
-                    M[ws + 1] = (SymT)(live >> 16);
-                    have = false;
-                    k = (int)atomicAdd(&s_next, 1u);
-                }
-                if (k < nL) {
-                    const uint32_t e = order[k];
-                    ws = (int)(e & 1023u);
-                    const int n = (int)(e >> 10);
-                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-                    if (BYTE_MODE) {
-                        cand = (uint32_t)bits64(rmask32, ws) & (live >> 1);
-                    } else {
-                        cand = 0;
-                        for (int i = 0; i + 1 < n; i++) {
-                            const uint32_t m =
-                                pair_lookup(T, Sym<SymT>::widen(S[ws + i]), Sym<SymT>::widen(S[ws + i + 1]));
-                            M[ws + i] = Sym<SymT>::narrow(m);
-                            if (m != SYM_NONE) cand |= 1u << i;
-                        }
-                    }
-                    br = 0xFFFFFFFFu;
-                    for (uint32_t c = cand; c; c &= c - 1) {
-                        const int i = __builtin_ctz(c);
-                        const SymT mv = M[ws + i];
-                        const uint32_t r = RK(Sym<SymT>::widen(mv));
-                        if (r < br) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
-                            br = r;
-                            bp = i;
-                            bm = mv;
-                        }
-                    }
-                    have = true;
-                }
+        const uint32_t mown = reinterpret_cast<const uint16_t*>(mergem)[lane];
+        uint32_t nM;
+        const uint32_t mbase = wave_excl_scan(__popc(mown), lane, &nM);
+        for (uint32_t r0 = 0; r0 < nM; r0 += 64) {
+            {
+                uint32_t mi = mbase - r0;
+                for (uint32_t m = mown; m; m &= m - 1, mi++)
+                    if (mi < 64u) stage[mi] = (uint16_t)(16 * lane + __builtin_ctz(m));
             }
-            if (!__any(have)) break;
+            __syncthreads();
+            bool have = r0 + lane < nM;
+            const int ws = have ? stage[lane] : 0;
+            SymT* Sw = S + ws;
+            SymT* Mw = M + ws;
+            uint32_t live = 0, cand = 0;  // lane words have at most 32 units
+            uint32_t br = 0xFFFFFFFFu;
+            int bp = 0;
+            SymT bm = 0;
             if (have) {
-                SymT* Sw = S + ws;
-                SymT* Mw = M + ws;
-                const int p = bp;
-                const uint32_t merged = Sym<SymT>::widen(bm);
-                // q: next live unit after p (exists: bit p of cand was set)
-                const uint32_t above = live & ~((2u << p) - 1u);
-                const int q = __builtin_ctz(above);
-                Sw[p] = bm;
-                live &= ~(1u << q);
-                cand &= ~((1u << q) | (1u << p));
-                const uint32_t right = above & (above - 1u);    // live units after q
-                const uint32_t left = live & ((1u << p) - 1u);  // live units before p
-                const int q2 = right ? __builtin_ctz(right) : 0;
-                const int p0 = left ? 31 - __builtin_clz(left) : 0;
-                const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
-                const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
-                // issue both first probes
-                const uint32_t h1 = pair_hash(merged, sr) & T.pair_mask;
-                const uint32_t h2 = pair_hash(sl, merged) & T.pair_mask;
-                const uint2 s1 = T.pair_slots[right ? h1 : 0u];  // unconditional loads: no exec juggling
-                const uint2 s2 = T.pair_slots[left ? h2 : 0u];
-                // rescan what the merge did not touch
-                if (left) cand &= ~(1u << p0);
-                br = 0xFFFFFFFFu;
+                const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
+                int n = nb;
+                if (!BYTE_MODE) {  // units = characters = lead bytes
+                    n = 0;
+                    for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
+                }
+                live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                if (BYTE_MODE) {
+                    cand = (uint32_t)bits64(rmask32, ws) & (live >> 1);
+                } else {
+                    for (int i = 0; i + 1 < n; i++) {
+                        const uint32_t m = pair_lookup(T, Sym<SymT>::widen(Sw[i]), Sym<SymT>::widen(Sw[i + 1]));
+                        Mw[i] = Sym<SymT>::narrow(m);
+                        if (m != SYM_NONE) cand |= 1u << i;
+                    }
+                }
                 for (uint32_t c = cand; c; c &= c - 1) {
                     const int i = __builtin_ctz(c);
                     const SymT mv = Mw[i];
                     const uint32_t r = RK(Sym<SymT>::widen(mv));
-                    if (r < br) {
+                    if (r < br) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
                         br = r;
                         bp = i;
                         bm = mv;
                     }
                 }
-                // the two new pairs
-                const uint32_t mr = right ? pair_resolve(T, s1, merged, sr, h1) : SYM_NONE;
-                const uint32_t ml = left ? pair_resolve(T, s2, sl, merged, h2) : SYM_NONE;
-                if (right) {
-                    const SymT mn = Sym<SymT>::narrow(mr);
-                    Mw[p] = mn;
-                    if (mr != SYM_NONE) {
-                        cand |= 1u << p;
-                        const uint32_t r = RK(mr);
-                        if (r < br || (r == br && p < bp)) {
+            }
+            for (;;) {
+                if (have && cand == 0) {
+                    // done: park the mask of surviving units (n >= 2 here, so Mw[1] is this word's own)
+                    Mw[0] = (SymT)(live & 0xFFFFu);
+                    Mw[1] = (SymT)(live >> 16);
+                    have = false;
+                }
+                if (!__any(have)) break;
+                if (have) {
+                    const int p = bp;
+                    const uint32_t merged = Sym<SymT>::widen(bm);
+                    // q: next live unit after p (exists: bit p of cand was set)
+                    const uint32_t above = live & ~((2u << p) - 1u);
+                    const int q = __builtin_ctz(above);
+                    Sw[p] = bm;
+                    live &= ~(1u << q);
+                    cand &= ~((1u << q) | (1u << p));
+                    const uint32_t right = above & (above - 1u);    // live units after q
+                    const uint32_t left = live & ((1u << p) - 1u);  // live units before p
+                    const int q2 = right ? __builtin_ctz(right) : 0;
+                    const int p0 = left ? 31 - __builtin_clz(left) : 0;
+                    const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
+                    const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
+                    // issue both first probes
+                    const uint32_t h1 = pair_hash(merged, sr) & T.pair_mask;
+                    const uint32_t h2 = pair_hash(sl, merged) & T.pair_mask;
+                    const uint2 s1 = T.pair_slots[right ? h1 : 0u];  // unconditional loads: no exec juggling
+                    const uint2 s2 = T.pair_slots[left ? h2 : 0u];
+                    // rescan what the merge did not touch
+                    if (left) cand &= ~(1u << p0);
+                    br = 0xFFFFFFFFu;
+                    for (uint32_t c = cand; c; c &= c - 1) {
+                        const int i = __builtin_ctz(c);
+                        const SymT mv = Mw[i];
+                        const uint32_t r = RK(Sym<SymT>::widen(mv));
+                        if (r < br) {
                             br = r;
-                            bp = p;
-                            bm = mn;
+                            bp = i;
+                            bm = mv;
                         }
                     }
-                }
-                if (left) {
-                    const SymT mn = Sym<SymT>::narrow(ml);
-                    Mw[p0] = mn;
-                    if (ml != SYM_NONE) {
-                        cand |= 1u << p0;
-                        const uint32_t r = RK(ml);
-                        if (r < br || (r == br && p0 < bp)) {
-                            br = r;
-                            bp = p0;
-                            bm = mn;
+                    // the two new pairs
+                    const uint32_t mr = right ? pair_resolve(T, s1, merged, sr, h1) : SYM_NONE;
+                    const uint32_t ml = left ? pair_resolve(T, s2, sl, merged, h2) : SYM_NONE;
+                    if (right) {
+                        const SymT mn = Sym<SymT>::narrow(mr);
+                        Mw[p] = mn;
+                        if (mr != SYM_NONE) {
+                            cand |= 1u << p;
+                            const uint32_t r = RK(mr);
+                            if (r < br || (r == br && p < bp)) {
+                                br = r;
+                                bp = p;
+                                bm = mn;
+                            }
+                        }
+                    }
+                    if (left) {
+                        const SymT mn = Sym<SymT>::narrow(ml);
+                        Mw[p0] = mn;
+                        if (ml != SYM_NONE) {
+                            cand |= 1u << p0;
+                            const uint32_t r = RK(ml);
+                            if (r < br || (r == br && p0 < bp)) {
+                                br = r;
+                                bp = p0;
+                                bm = mn;
+                            }
                         }
                     }
                 }
             }
+            __syncthreads();
         }
     }
-    __syncthreads();
     HUTK_STAMP(5);
 
     // ---- 7. per-position epilogue: counts -> scan -> ids out, exception records ----
     // M[word start] now holds: EXC_MARK (exception word), 1 (single unit / whole-word hit), or -- for the
-    // words of the merge loop (missbits) -- the low half of the survivor mask (high half in the next slot)
-    auto survivors = [&](int ws, uint32_t wi, bool* is_exc) -> uint32_t {
+    // words of the merge loop (mergem bit) -- the low half of the survivor mask (high half in the next slot)
+    auto survivors = [&](int ws, bool* is_exc) -> uint32_t {
         const uint32_t lo = M[ws];
-        if ((missbits[wi >> 5] >> (wi & 31)) & 1u) {
+        if ((mergem[ws >> 5] >> (ws & 31)) & 1u) {
             *is_exc = false;
             return lo | ((uint32_t)M[ws + 1] << 16);
         }
@@ -626,17 +598,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         return *is_exc ? 0u : 1u;
     };
     uint32_t mine = 0;  // low 16: ids, high 16: exception words
-    {
-        uint32_t wi = wbase;
-        for (uint32_t m = own; m; m &= m - 1, wi++) {
-            bool is_exc;
-            const uint32_t sv = survivors(16 * lane + __builtin_ctz(m), wi, &is_exc);
-            mine += is_exc ? 0x10000u : (uint32_t)__popc(sv);
-        }
+    for (uint32_t m = own; m; m &= m - 1) {
+        bool is_exc;
+        const uint32_t sv = survivors(16 * lane + __builtin_ctz(m), &is_exc);
+        mine += is_exc ? 0x10000u : (uint32_t)__popc(sv);
     }
     uint32_t total;
     uint32_t run = wave_excl_scan(mine, lane, &total);
-    lanepref[lane] = (run & 0xFFFFu) | (wbase << 16);  // ids before this lane's words | index of its first word
+    lanepref[lane] = (uint16_t)run;  // ids before this lane's words
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
     const unsigned long long has_words = __ballot(own != 0);
     const int first_lane = has_words ? __builtin_ctzll(has_words) : 0;
@@ -654,37 +623,34 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
     int32_t* run_out = W.run + t0 + run_start;
-    {
-        uint32_t wi = wbase;
-        for (uint32_t m = own; m; m &= m - 1, wi++) {
-            const int ws = 16 * lane + __builtin_ctz(m);
-            bool is_exc;
-            uint32_t sv = survivors(ws, wi, &is_exc);
-            uint32_t pos = run & 0xFFFFu;
-            if (is_exc) {
-                const uint64_t slot = (uint64_t)exc_first + (run >> 16);
-                if ((int64_t)slot < W.cap_exc) {
-                    const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-                    const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-                    const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
-                    ExcRec rec;
-                    rec.ws = t0 + ws;
-                    rec.tok_base = 0;
-                    rec.out_pos = 0;
-                    rec.len = known_end ? nb : -1;
-                    rec.wpos = pos;
-                    rec.cnt = 0;
-                    rec.tile = (uint32_t)tile;
-                    W.exc[slot] = rec;
-                } else {
-                    raise(A.err, HUTK_E_MEMORY);
-                }
-                run += 0x10000u;
+    for (uint32_t m = own; m; m &= m - 1) {
+        const int ws = 16 * lane + __builtin_ctz(m);
+        bool is_exc;
+        uint32_t sv = survivors(ws, &is_exc);
+        uint32_t pos = run & 0xFFFFu;
+        if (is_exc) {
+            const uint64_t slot = (uint64_t)exc_first + (run >> 16);
+            if ((int64_t)slot < W.cap_exc) {
+                const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+                const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                ExcRec rec;
+                rec.ws = t0 + ws;
+                rec.tok_base = 0;
+                rec.out_pos = 0;
+                rec.len = known_end ? nb : -1;
+                rec.wpos = pos;
+                rec.cnt = 0;
+                rec.tile = (uint32_t)tile;
+                W.exc[slot] = rec;
             } else {
-                run += (uint32_t)__popc(sv);
-                for (; sv; sv &= sv - 1)  // surviving units, left to right
-                    run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(S[ws + __builtin_ctz(sv)]));
+                raise(A.err, HUTK_E_MEMORY);
             }
+            run += 0x10000u;
+        } else {
+            run += (uint32_t)__popc(sv);
+            for (; sv; sv &= sv - 1)  // surviving units, left to right
+                run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(S[ws + __builtin_ctz(sv)]));
         }
     }
     __syncthreads();
@@ -697,12 +663,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (o < t0) continue;
         const int r = (int)(o - t0);
         const int lr = r >> 4;
-        uint32_t before = lanepref[lr] & 0xFFFFu;
-        uint32_t wi = lanepref[lr] >> 16;
+        uint32_t before = lanepref[lr];
         uint32_t fl = wmask16[lr] & ((1u << (r & 15)) - 1u);
-        for (; fl; fl &= fl - 1, wi++) {
+        for (; fl; fl &= fl - 1) {
             bool is_exc;
-            before += (uint32_t)__popc(survivors(16 * lr + __builtin_ctz(fl), wi, &is_exc));
+            before += (uint32_t)__popc(survivors(16 * lr + __builtin_ctz(fl), &is_exc));
         }
         W.doc_tile_pos[d] = before;
     }
