@@ -246,12 +246,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
     __shared__ uint32_t docm[WINDOW / 32 + 3];
     __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
-    __shared__ __attribute__((aligned(8))) uint16_t rmask16[64 + 8];  // pair (r, r+1) has a rank
     __shared__ __attribute__((aligned(8))) uint32_t mergem[NPOS / 32 + 2];  // positions whose word needs the merge loop
     __shared__ uint16_t stage[64];                                      // word starts handed to the lanes, 64 at a time
     __shared__ __attribute__((aligned(16))) SymT S[NPOS];
     __shared__ __attribute__((aligned(16))) SymT M[NPOS];
-    __shared__ SymT s_item_sym[256];
+    __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     __shared__ uint16_t lanepref[64];  // ids before lane l's positions
 
@@ -264,7 +263,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
     const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
-    const uint32_t* rmask32 = reinterpret_cast<const uint32_t*>(rmask16);
     HUTK_STAMP(0);
 
     // ---- 1. stage bytes and tables ------------------------------------------------
@@ -279,13 +277,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
         }
     }
-    for (int i = lane; i < 256; i += 64) {
-        s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
-        if (!BYTE_MODE) s_item_direct[i] = T.item_direct[i];
-    }
+    if (!BYTE_MODE)
+        for (int i = lane; i < 256; i += 64) {
+            s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
+            s_item_direct[i] = T.item_direct[i];
+        }
     if (lane < WINDOW / 32 + 3) docm[lane] = 0;
     if (lane < NPOS / 32 + 2) mergem[lane] = 0;
-    if (lane < 8) { wmask16[64 + lane] = 0xFFFFu; rmask16[64 + lane] = 0; }
+    if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
     __syncthreads();
 
     // ---- 2. document starts inside the window -------------------------------
@@ -325,28 +324,6 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     wmask16[lane] = (uint16_t)flags;
     HUTK_STAMP(2);
 
-    // ---- 4. byte mode: symbols and initial pair ranks for all 16 positions at once ---
-    uint32_t rbits = 0;
-    if (BYTE_MODE) {
-        uint32_t nf = __shfl_down(flags, 1, 64) & 1u;
-        if (lane == 63) nf = 1u;
-        const uint32_t fl17 = flags | (nf << 16);
-        const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
-        SymT sv[16], mv[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const uint32_t b = win_byte(w, 8 + j), b2 = win_byte(w, 9 + j);
-            sv[j] = s_item_sym[b];
-            mv[j] = ((fl17 >> (j + 1)) & 1u) ? Sym<SymT>::NONE : bp[(b << 8) | b2];
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            S[16 * lane + j] = sv[j];
-            M[16 * lane + j] = mv[j];
-            rbits |= (uint32_t)(mv[j] != Sym<SymT>::NONE) << j;
-        }
-        rmask16[lane] = (uint16_t)rbits;
-    }
     __syncthreads();
     HUTK_STAMP(3);
 
@@ -413,7 +390,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             if (exc) {
                 M[ws] = (SymT)EXC_MARK;
                 done = true;
-            } else if (n == 1) {  // a single unit: nothing to merge, its symbol already sits in S[ws]
+            } else if (n == 1) {  // a single unit: nothing to merge
+                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(T.item_sym[sb[ws + LOOKBACK]]);
                 M[ws] = (SymT)1;
                 done = true;
             } else if (BYTE_MODE && T.word_mask && nb <= 16) {
@@ -489,7 +467,30 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 }
                 live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
                 if (BYTE_MODE) {
-                    cand = (uint32_t)bits64(rmask32, ws) & (live >> 1);
+                    // symbols (byte -> symbol LUT) and initial pair results (65536-entry byte-pair table) of
+                    // THIS word only: ~11 % of the words get here, the rest never touch these tables
+                    const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
+                    const uint8_t* wb = sb + ws + LOOKBACK;
+                    for (int i0 = 0; i0 < n; i0 += 8) {
+                        uint32_t sv[8];
+                        SymT mv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {  // 16 independent loads in flight
+                            const int i = i0 + j;
+                            const uint32_t b = (i < n) ? wb[i] : 0u, b2 = (i + 1 < n) ? wb[i + 1] : 0u;
+                            sv[j] = T.item_sym[b];
+                            mv[j] = bp[(b << 8) | b2];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const int i = i0 + j;
+                            if (i < n) {
+                                Sw[i] = Sym<SymT>::narrow(sv[j]);
+                                Mw[i] = mv[j];
+                                if (i + 1 < n && mv[j] != Sym<SymT>::NONE) cand |= 1u << i;
+                            }
+                        }
+                    }
                 } else {
                     for (int i = 0; i + 1 < n; i++) {
                         const uint32_t m = pair_lookup(T, Sym<SymT>::widen(Sw[i]), Sym<SymT>::widen(Sw[i + 1]));
