@@ -170,7 +170,7 @@ int pad_per_doc(const hutk_ctx* c) {
 // tile metadata packs five uint32 arrays and two int64 arrays into two allocations
 int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_tiles, Workspace& W) {
     const int64_t pad = pad_per_doc(c);
-    const size_t run_elems = (size_t)(n_tiles * TILE_BYTES + 512);
+    const size_t run_elems = (size_t)(n_tiles * RUN_STRIDE + 512);
     const size_t exc_elems = (size_t)(n_bytes + pad * (n_docs + 2) + 512);
     HIP_TRY(c->w_run.reserve(run_elems));
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));

@@ -18,6 +18,11 @@ constexpr int TAIL = 16;           // look-ahead for the last halo positions
 constexpr int WINDOW = LOOKBACK + TILE_BYTES + HALO + TAIL;  // 1056 staged bytes
 constexpr int LANE_MAX_UNITS = 32;   // longest word a single lane merges (32-bit live/candidate masks)
 constexpr int LANE_MAX_BYTES = 63;   // and its byte length (its end must be within 63 positions)
+// ids of one tile's words sit at run[tile * RUN_STRIDE + (first word start) + k]: at most one id per byte of
+// the words that START in the tile (the last may overhang by LANE_MAX_BYTES), plus up to RUN_EXTRA ids of
+// prefix units / prefix-alone ids granted to document-first words (beyond that budget: exception path)
+constexpr int RUN_EXTRA = 64;
+constexpr int RUN_STRIDE = TILE_BYTES + 64 + RUN_EXTRA;
 constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units merge in LDS
 
 // per-position codes produced by the classifier (parser.c:24-183 restated as a

@@ -253,6 +253,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     __shared__ uint16_t lanepref[64];  // ids before lane l's positions
+    // non-byte mode with a prefix: the first word of a document gets the prefix units in front of its own,
+    // which does not fit its byte span; up to ARENA_WORDS such words per tile merge in this side arena
+    // (more than that: exception path)
+    constexpr int ARENA_WORDS = 4, ARENA_W = LANE_MAX_UNITS + 4;
+    __shared__ SymT arenaS[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
+    __shared__ SymT arenaM[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
+    __shared__ uint16_t arena_ws[ARENA_WORDS], arena_n[ARENA_WORDS];
+    __shared__ uint32_t s_arena_used, s_extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
 
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -284,6 +292,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         }
     if (lane < WINDOW / 32 + 3) docm[lane] = 0;
     if (lane < NPOS / 32 + 2) mergem[lane] = 0;
+    if (lane == 0) { s_arena_used = 0; s_extra = 0; }
+    if (lane < ARENA_WORDS) arena_ws[lane] = 0xFFFFu;
     if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
     __syncthreads();
 
@@ -355,8 +365,27 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
             const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
             const bool docfirst = bit_at(docm, ws + LOOKBACK);
-            bool exc = !known_end || nb > LANE_MAX_BYTES || (T.has_prefix && docfirst);
+            // first word of a document with a prefix configured (core.c:364-366, 421-451): a leading space
+            // means "prefix ids as a word of their own, then the word as it is" (handled in the epilogue);
+            // otherwise the prefix units go in front of the word's own units (arena)
+            const bool pfx = T.has_prefix && docfirst && sb[ws + LOOKBACK] != ' ';
+            bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
             int n = 0;
+            SymT* Sdst = S + ws;
+            int slot = -1;
+            if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
+                exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
+            if (!exc && pfx) {
+                slot = (int)atomicAdd(&s_arena_used, 1u);
+                if (slot >= ARENA_WORDS ||
+                    atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
+                else {
+                    Sdst = arenaS + slot * ARENA_W;
+                    for (int i = 0; i < T.n_prefix && i < ARENA_W; i++) Sdst[i] = Sym<SymT>::narrow(T.prefix_syms[i]);
+                    n = T.n_prefix;
+                }
+            }
+            const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
             if (!exc) {
                 if (BYTE_MODE) {
                     n = nb;
@@ -379,7 +408,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                             if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
                             sym = char_lookup(T, packed);
                         }
-                        if (n < LANE_MAX_UNITS) S[ws + n] = Sym<SymT>::narrow(sym);
+                        if (n < n_cap) Sdst[n] = Sym<SymT>::narrow(sym);
                         n++;
                         i += L;
                     }
@@ -387,7 +416,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 if (n > LANE_MAX_UNITS) exc = true;
             }
             bool done = false;
-            if (exc) {
+            if (!exc && pfx) {  // arena word: always at least two units, always through the merge loop
+                arena_ws[slot] = (uint16_t)ws;
+                arena_n[slot] = (uint16_t)n;
+            } else if (exc) {
                 M[ws] = (SymT)EXC_MARK;
                 done = true;
             } else if (n == 1) {  // a single unit: nothing to merge
@@ -454,6 +486,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             const int ws = have ? stage[lane] : 0;
             SymT* Sw = S + ws;
             SymT* Mw = M + ws;
+            int n_arena = 0;
+            if (!BYTE_MODE && have)
+                for (int a = 0; a < ARENA_WORDS; a++)
+                    if (arena_ws[a] == ws) {
+                        Sw = arenaS + a * ARENA_W;
+                        Mw = arenaM + a * ARENA_W;
+                        n_arena = arena_n[a];
+                    }
             uint32_t live = 0, cand = 0;  // lane words have at most 32 units
             uint32_t br = 0xFFFFFFFFu;
             int bp = 0;
@@ -461,9 +501,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             if (have) {
                 const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
                 int n = nb;
-                if (!BYTE_MODE) {  // units = characters = lead bytes
+                if (!BYTE_MODE) {  // units = characters = lead bytes (+ the prefix units of an arena word)
                     n = 0;
                     for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
+                    if (n_arena) n = n_arena;
                 }
                 live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
                 if (BYTE_MODE) {
@@ -589,20 +630,33 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     // ---- 7. per-position epilogue: counts -> scan -> ids out, exception records ----
     // M[word start] now holds: EXC_MARK (exception word), 1 (single unit / whole-word hit), or -- for the
     // words of the merge loop (mergem bit) -- the low half of the survivor mask (high half in the next slot)
-    auto survivors = [&](int ws, bool* is_exc) -> uint32_t {
+    auto survivors = [&](int ws, bool* is_exc, const SymT** base) -> uint32_t {
+        *base = S + ws;
+        *is_exc = false;
+        if (!BYTE_MODE)
+            for (int a = 0; a < ARENA_WORDS; a++)
+                if (arena_ws[a] == ws) {
+                    *base = arenaS + a * ARENA_W;
+                    return (uint32_t)arenaM[a * ARENA_W] | ((uint32_t)arenaM[a * ARENA_W + 1] << 16);
+                }
         const uint32_t lo = M[ws];
-        if ((mergem[ws >> 5] >> (ws & 31)) & 1u) {
-            *is_exc = false;
-            return lo | ((uint32_t)M[ws + 1] << 16);
-        }
+        if ((mergem[ws >> 5] >> (ws & 31)) & 1u) return lo | ((uint32_t)M[ws + 1] << 16);
         *is_exc = lo == EXC_MARK;
         return *is_exc ? 0u : 1u;
+    };
+    // ids of the prefix encoded as a word of its own, emitted before a document-first word that starts
+    // with a space (core.c:421-446)
+    auto alone_ids = [&](int ws) -> uint32_t {
+        if (BYTE_MODE || !T.has_prefix) return 0u;
+        return (bit_at(docm, ws + LOOKBACK) && sb[ws + LOOKBACK] == ' ') ? (uint32_t)T.n_prefix_alone : 0u;
     };
     uint32_t mine = 0;  // low 16: ids, high 16: exception words
     for (uint32_t m = own; m; m &= m - 1) {
         bool is_exc;
-        const uint32_t sv = survivors(16 * lane + __builtin_ctz(m), &is_exc);
-        mine += is_exc ? 0x10000u : (uint32_t)__popc(sv);
+        const SymT* base;
+        const int ws = 16 * lane + __builtin_ctz(m);
+        const uint32_t sv = survivors(ws, &is_exc, &base);
+        mine += is_exc ? 0x10000u : ((uint32_t)__popc(sv) + alone_ids(ws));
     }
     uint32_t total;
     uint32_t run = wave_excl_scan(mine, lane, &total);
@@ -623,11 +677,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    int32_t* run_out = W.run + t0 + run_start;
+    int32_t* run_out = W.run + tile * RUN_STRIDE + run_start;
     for (uint32_t m = own; m; m &= m - 1) {
         const int ws = 16 * lane + __builtin_ctz(m);
         bool is_exc;
-        uint32_t sv = survivors(ws, &is_exc);
+        const SymT* base;
+        uint32_t sv = survivors(ws, &is_exc, &base);
         uint32_t pos = run & 0xFFFFu;
         if (is_exc) {
             const uint64_t slot = (uint64_t)exc_first + (run >> 16);
@@ -649,9 +704,11 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
             run += 0x10000u;
         } else {
-            run += (uint32_t)__popc(sv);
+            const uint32_t na = alone_ids(ws);
+            run += (uint32_t)__popc(sv) + na;
+            for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_ids[i];
             for (; sv; sv &= sv - 1)  // surviving units, left to right
-                run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(S[ws + __builtin_ctz(sv)]));
+                run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(base[__builtin_ctz(sv)]));
         }
     }
     __syncthreads();
@@ -668,7 +725,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         uint32_t fl = wmask16[lr] & ((1u << (r & 15)) - 1u);
         for (; fl; fl &= fl - 1) {
             bool is_exc;
-            before += (uint32_t)__popc(survivors(16 * lr + __builtin_ctz(fl), &is_exc));
+            const SymT* base;
+            const int wp = 16 * lr + __builtin_ctz(fl);
+            const uint32_t sv = survivors(wp, &is_exc, &base);
+            if (!is_exc) before += (uint32_t)__popc(sv) + alone_ids(wp);
         }
         W.doc_tile_pos[d] = before;
     }
@@ -1010,7 +1070,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspac
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
     const uint32_t nexc = W.tile_nexc[tile];
-    const int32_t* run = W.run + tile * TILE_BYTES + W.tile_run_start[tile];
+    const int32_t* run = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
     if (base + (int64_t)W.tile_count[tile] > A.ids_cap) {
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
         return;

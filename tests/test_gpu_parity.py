@@ -139,6 +139,33 @@ def test_random_text_char_mode_with_prefix(small_char):
         _compare(ctx, orc, docs, f"char{k}")
 
 
+def test_prefix_on_document_first_words(tmp_path, oracle_mod):
+    """Prefix handling of a document's first word (core.c:364-366, 421-451) in the tile kernel's side
+    arena and, past its capacity, the exception path: documents packed denser than the arena holds, first
+    words at the unit limit, multi-unit prefixes, the leading-space form, byte mode with a prefix."""
+    rng = random.Random(17)
+    short = [rng.choice(["a", " a", "ab", "é", " é", "", " ", "\n", "漢", "word", " word", "Szia!"]).encode()
+             for _ in range(4000)]
+    limit = []
+    for n in range(26, 40):
+        limit.append(("e" * n).encode())
+        limit.append((" " + "t" * n).encode())
+        limit.append(("ő" * n + " tail").encode())
+    text = [H.random_text(rng, max_words=12).encode("utf-8") for _ in range(3000)]
+    spaced = [b" " + H.random_text(rng, max_words=5).encode("utf-8") for _ in range(1000)]
+    for seed, prefix, is_byte in [(1, "▁", False), (2, "▁▁", False), (3, "ab", False), (4, "et a", False),
+                                  (5, "Ġ", True), (6, "xy", True)]:
+        if is_byte:
+            ents, sp = H.random_byte_vocab(seed, n_merges=400)
+        else:
+            ents, sp = H.random_char_vocab(seed, n_merges=400)
+        vp, spath = H.write_vocab(tmp_path, f"p{seed}", ents, sp)
+        ctx = _ctx(vp, spath, prefix, is_byte)
+        orc = oracle_mod.Oracle(vp, spath, prefix, is_byte)
+        for name, docs in [("short", short), ("limit", limit), ("text", text), ("spaced", spaced)]:
+            _compare(ctx, orc, docs, f"prefix[{prefix!r},{is_byte}]/{name}")
+
+
 def test_long_words_char_mode(small_char):
     rng = random.Random(13)
     docs = []
