@@ -239,9 +239,13 @@ int build_word_table(hutk_ctx* c) {
     if (!n) return HUTK_OK;
     std::vector<int64_t> offs(n + 1), oo(n + 1);
     for (size_t i = 0; i <= n; i++) offs[i] = T.cand_off[i];
-    std::vector<int32_t> ids(T.cand_bytes.size() + 1);
+    std::vector<int32_t> ids(T.cand_bytes.size() + (size_t)pad_per_doc(c) * n + 1);
+    // candidates are encoded one per document, as words that are NOT first in their document: no prefix
+    const int had_prefix = c->dt.has_prefix;
+    c->dt.has_prefix = 0;
     int rc = hutk_encode_batch(c, T.cand_bytes.data(), offs.data(), (int64_t)n, ids.data(), (int64_t)ids.size(),
                                oo.data(), nullptr);
+    c->dt.has_prefix = had_prefix;
     if (rc) return rc;
     std::vector<size_t> keep;
     for (size_t i = 0; i < n; i++)

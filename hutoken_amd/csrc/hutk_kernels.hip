@@ -370,63 +370,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             // otherwise the prefix units go in front of the word's own units (arena)
             const bool pfx = T.has_prefix && docfirst && sb[ws + LOOKBACK] != ' ';
             bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
-            int n = 0;
-            SymT* Sdst = S + ws;
-            int slot = -1;
             if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
                 exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
-            if (!exc && pfx) {
-                slot = (int)atomicAdd(&s_arena_used, 1u);
-                if (slot >= ARENA_WORDS ||
-                    atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
-                else {
-                    Sdst = arenaS + slot * ARENA_W;
-                    for (int i = 0; i < T.n_prefix && i < ARENA_W; i++) Sdst[i] = Sym<SymT>::narrow(T.prefix_syms[i]);
-                    n = T.n_prefix;
-                }
-            }
-            const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
-            if (!exc) {
-                if (BYTE_MODE) {
-                    n = nb;
-                } else {
-                    const int lw = ws + LOOKBACK;
-                    int i = 0;
-                    while (i < nb) {
-                        const uint32_t b = sb[lw + i];
-                        int L = 1;
-                        if (b >= 0x80u) {
-                            L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
-                            if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
-                        }
-                        uint32_t sym;
-                        if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
-                        else if (L == 1) sym = SYM_UNK;
-                        else {
-                            uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
-                            if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
-                            if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
-                            sym = char_lookup(T, packed);
-                        }
-                        if (n < n_cap) Sdst[n] = Sym<SymT>::narrow(sym);
-                        n++;
-                        i += L;
-                    }
-                }
-                if (n > LANE_MAX_UNITS) exc = true;
-            }
             bool done = false;
-            if (!exc && pfx) {  // arena word: always at least two units, always through the merge loop
-                arena_ws[slot] = (uint16_t)ws;
-                arena_n[slot] = (uint16_t)n;
-            } else if (exc) {
-                M[ws] = (SymT)EXC_MARK;
-                done = true;
-            } else if (n == 1) {  // a single unit: nothing to merge
-                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(T.item_sym[sb[ws + LOOKBACK]]);
-                M[ws] = (SymT)1;
-                done = true;
-            } else if (BYTE_MODE && T.word_mask && nb <= 16) {
+            if (!exc && !pfx && T.word_mask && nb >= 2 && nb <= 16) {
                 // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
                 // token it encodes to.  Entries were verified by this pipeline at context creation.
                 const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
@@ -459,6 +406,61 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     S[ws] = Sym<SymT>::narrow(hsym);
                     M[ws] = (SymT)1;
                 }
+            }
+            int n = 0;
+            SymT* Sdst = S + ws;
+            int slot = -1;
+            if (!exc && pfx) {
+                slot = (int)atomicAdd(&s_arena_used, 1u);
+                if (slot >= ARENA_WORDS ||
+                    atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
+                else {
+                    Sdst = arenaS + slot * ARENA_W;
+                    for (int i = 0; i < T.n_prefix && i < ARENA_W; i++) Sdst[i] = Sym<SymT>::narrow(T.prefix_syms[i]);
+                    n = T.n_prefix;
+                }
+            }
+            const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
+            if (!exc && !done) {
+                if (BYTE_MODE) {
+                    n = nb;
+                } else {
+                    const int lw = ws + LOOKBACK;
+                    int i = 0;
+                    while (i < nb) {
+                        const uint32_t b = sb[lw + i];
+                        int L = 1;
+                        if (b >= 0x80u) {
+                            L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                            if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
+                        }
+                        uint32_t sym;
+                        if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
+                        else if (L == 1) sym = SYM_UNK;
+                        else {
+                            uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
+                            if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
+                            if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
+                            sym = char_lookup(T, packed);
+                        }
+                        if (n < n_cap) Sdst[n] = Sym<SymT>::narrow(sym);
+                        n++;
+                        i += L;
+                    }
+                }
+                if (n > LANE_MAX_UNITS) exc = true;
+            }
+            if (done) {
+            } else if (!exc && pfx) {  // arena word: always at least two units, always through the merge loop
+                arena_ws[slot] = (uint16_t)ws;
+                arena_n[slot] = (uint16_t)n;
+            } else if (exc) {
+                M[ws] = (SymT)EXC_MARK;
+                done = true;
+            } else if (n == 1) {  // a single unit: nothing to merge
+                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(T.item_sym[sb[ws + LOOKBACK]]);
+                M[ws] = (SymT)1;
+                done = true;
             }
             if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
         }

@@ -368,12 +368,16 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
             }
     }
 
-    // ---- byte-encoder mode: keys as raw input bytes (whole-word table candidates) ----
-    if (is_byte_encoder && !T.has_prefix) {
-        // unit string -> the one input byte that produces it (ambiguous units disable the table)
+    // ---- keys as raw input bytes (whole-word table candidates) ----
+    // A key is a candidate when every unit of it is produced by exactly one input: the single byte whose
+    // pretokenizer output is that unit, or (non-byte mode) the multi-byte character itself.  Whether the
+    // raw bytes really are one word that encodes to the key's id is decided on the device when the context
+    // is created (hutk_api.cpp build_word_table); a wrong guess here only costs a dropped candidate.
+    {
         std::unordered_map<uint32_t, int> byte_of_sym;
         bool ambiguous = false;
         for (int b = 1; b < 256; b++) {
+            if (!T.item_direct[b]) continue;  // lead byte of a character looked up in the char table
             auto ins = byte_of_sym.emplace(T.item_sym[b], b);
             if (!ins.second) ambiguous = true;
         }
@@ -389,10 +393,12 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
                     auto it = sym_of.find(u);
                     if (it == sym_of.end()) { ok = false; break; }
                     auto bt = byte_of_sym.find(it->second);
-                    if (bt == byte_of_sym.end()) { ok = false; break; }
-                    raw.push_back((char)bt->second);
+                    if (bt != byte_of_sym.end()) raw.push_back((char)bt->second);
+                    else if (!is_byte_encoder && u.size() >= 2 && u.size() <= 4 &&
+                             (size_t)lead_len((unsigned char)u[0]) == u.size()) raw += u;
+                    else { ok = false; break; }
                 }
-                if (!ok) continue;
+                if (!ok || raw.size() < 2 || raw.size() > 16) continue;
                 T.cand_bytes.insert(T.cand_bytes.end(), raw.begin(), raw.end());
                 T.cand_off.push_back((uint32_t)T.cand_bytes.size());
                 T.cand_sym.push_back((uint32_t)i);
