@@ -252,18 +252,29 @@ int build_word_table(hutk_ctx* c) {
         if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
             keep.push_back(i);
     if (keep.empty()) return HUTK_OK;
+    // two-choice cuckoo table (hutk_internal.h); a word that cannot be placed is simply left out
     uint32_t cap = 1024;
-    while (cap < keep.size() * 2 + 16) cap <<= 1;
-    std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
-    std::vector<uint32_t> syms(cap, 0);
-    for (size_t i : keep) {
+    while (cap < keep.size() * 5 / 2 + 16) cap <<= 1;
+    std::vector<uint4> kk(keep.size());
+    for (size_t q = 0; q < keep.size(); q++) {
+        const size_t i = keep[q];
         uint32_t k[4] = {0, 0, 0, 0};
         const size_t len = (size_t)(offs[i + 1] - offs[i]);
         for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
-        uint32_t h = word_hash(k[0], k[1], k[2], k[3]) & (cap - 1);
-        while (keys[h].x != 0) h = (h + 1) & (cap - 1);
-        keys[h] = make_uint4(k[0], k[1], k[2], k[3]);
-        syms[h] = T.cand_sym[i];
+        kk[q] = make_uint4(k[0], k[1], k[2], k[3]);
+    }
+    std::vector<uint32_t> where, homeless;
+    cuckoo_place(keep.size(), cap,
+                 [&](uint32_t q) { return word_hash(kk[q].x, kk[q].y, kk[q].z, kk[q].w); },
+                 [&](uint32_t q) { return word_hash2(kk[q].x, kk[q].y, kk[q].z, kk[q].w); }, where, &homeless);
+    std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
+    std::vector<uint32_t> syms(cap, 0);
+    size_t placed = 0;
+    for (size_t q = 0; q < keep.size(); q++) {
+        if (where[q] == 0xFFFFFFFFu) continue;
+        keys[where[q]] = kk[q];
+        syms[where[q]] = T.cand_sym[keep[q]];
+        placed++;
     }
     HIP_TRY(c->d_word_keys.reserve(cap));
     HIP_TRY(c->d_word_syms.reserve(cap));
@@ -272,7 +283,7 @@ int build_word_table(hutk_ctx* c) {
     c->dt.word_keys = c->d_word_keys.p;
     c->dt.word_syms = c->d_word_syms.p;
     c->dt.word_mask = cap - 1;
-    c->n_word_entries = (int64_t)keep.size();
+    c->n_word_entries = (int64_t)placed;
     return HUTK_OK;
 }
 

@@ -46,11 +46,72 @@ HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) {
     h ^= h >> 7;
     return h;
 }
+// Every hashed table here is a two-choice cuckoo table: a key lives in slot hash(key) or slot hash2(key)
+// and nowhere else, so a lookup is two INDEPENDENT loads issued together and never a dependent probe
+// sequence -- a wavefront pays for the slowest of its 64 lanes, and with linear probing some lane almost
+// always needed a second or third round trip.
+HUTK_HD uint32_t pair_hash2(uint32_t l, uint32_t r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t h = (__umul24(l, 0xC2B2AEu) + 0x27D4EB2Fu) ^ __umul24(r, 0x7FEB35u);
+#else
+    uint32_t h = ((uint32_t)((uint64_t)(l & 0xFFFFFFu) * 0xC2B2AEu) + 0x27D4EB2Fu) ^
+                 (uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x7FEB35u);
+#endif
+    h ^= h >> 13;
+    h ^= h >> 6;
+    return h;
+}
 // whole-word table: 16 raw bytes (zero padded) as four dwords
 HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     uint32_t x = k0 ^ ((k1 << 13) | (k1 >> 19)) ^ ((k2 << 7) | (k2 >> 25)) ^ ((k3 << 21) | (k3 >> 11));
     x *= 0x9E3779B1u;
     return x ^ (x >> 15);
+}
+HUTK_HD uint32_t word_hash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+    uint32_t x = k3 ^ ((k0 << 11) | (k0 >> 21)) ^ ((k1 << 23) | (k1 >> 9)) ^ ((k2 << 17) | (k2 >> 15));
+    x *= 0x85EBCA6Bu;
+    return x ^ (x >> 13);
+}
+
+// Two-choice cuckoo placement of n keys into `cap` (power of two) single-entry slots.  h1/h2 give the two
+// slots of key i; on return where[i] is the slot it got.  False when some key could not be placed
+// (the caller grows the table or, for an optional table, drops the key).
+template <class H1, class H2>
+static inline bool cuckoo_place(size_t n, uint32_t cap, H1 h1, H2 h2, std::vector<uint32_t>& where,
+                                std::vector<uint32_t>* failed = nullptr) {
+    const uint32_t NONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> owner(cap, NONE);
+    where.assign(n, NONE);
+    bool all = true;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t cur = (uint32_t)i;
+        uint32_t slot = h1(cur) & (cap - 1);
+        bool placed = false;
+        for (int kick = 0; kick < 2000; kick++) {
+            const uint32_t a = h1(cur) & (cap - 1), b = h2(cur) & (cap - 1);
+            if (owner[a] == NONE) slot = a;
+            else if (owner[b] == NONE) slot = b;
+            else {
+                // evict: take the slot we did not just come from, or a random one
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                slot = (slot == a) ? b : (slot == b) ? a : ((rng >> 33) & 1u ? a : b);
+            }
+            const uint32_t prev = owner[slot];
+            owner[slot] = cur;
+            where[cur] = slot;
+            if (prev == NONE) { placed = true; break; }
+            where[prev] = NONE;
+            cur = prev;
+        }
+        if (!placed) {
+            // `cur` is homeless: the walk did not converge
+            all = false;
+            if (!failed) return false;
+            failed->push_back(cur);
+        }
+    }
+    return all;
 }
 HUTK_HD uint32_t char_hash(uint32_t packed) {
     uint32_t h = packed * 0x9E3779B1u;

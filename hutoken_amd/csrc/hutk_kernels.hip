@@ -46,20 +46,26 @@ namespace hutk {
 // ------------------------------------------------------------------------
 // table lookups
 // ------------------------------------------------------------------------
-// pair slot: x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8 (hutk_internal.h)
-__device__ __forceinline__ uint32_t pair_resolve(const DevTables& T, uint2 s, uint32_t l, uint32_t r, uint32_t h) {
+// pair slot: x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8 (hutk_internal.h).
+// Two-choice cuckoo table: the pair is in slot hash or slot hash2 or absent.
+struct PairProbe { uint2 a, b; };
+__device__ __forceinline__ PairProbe pair_issue(const DevTables& T, uint32_t l, uint32_t r) {
+    PairProbe p;
+    p.a = T.pair_slots[pair_hash(l, r) & T.pair_mask];
+    p.b = T.pair_slots[pair_hash2(l, r) & T.pair_mask];
+    return p;
+}
+__device__ __forceinline__ uint32_t pair_resolve(const PairProbe& p, uint32_t l, uint32_t r) {
     const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
-    for (;;) {
-        // empty first: (SYM_UNK, SYM_UNK) has the same bit pattern as an empty slot
-        if (s.x == 0xFFFFFFFFu) return SYM_NONE;
-        if (s.x == k0 && (s.y & 0xFFu) == k1) return s.y >> 8;
-        h = (h + 1) & T.pair_mask;
-        s = T.pair_slots[h];
-    }
+    // an empty slot is all ones, which is also the key pattern of (SYM_UNK, SYM_UNK): its merged field
+    // then reads 0xFFFFFF, which no entry has
+    uint32_t y = 0xFFFFFFFFu;
+    if (p.a.x == k0 && (p.a.y & 0xFFu) == k1) y = p.a.y;
+    if (p.b.x == k0 && (p.b.y & 0xFFu) == k1) y = p.b.y;
+    return y == 0xFFFFFFFFu ? SYM_NONE : y >> 8;
 }
 __device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, uint32_t r) {
-    const uint32_t h = pair_hash(l, r) & T.pair_mask;
-    return pair_resolve(T, T.pair_slots[h], l, r, h);
+    return pair_resolve(pair_issue(T, l, r), l, r);
 }
 
 __device__ __forceinline__ uint32_t char_lookup(const DevTables& T, uint32_t packed) {
@@ -393,15 +399,15 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
                 else if (full == 2) { k2 &= keep; k3 = 0; }
                 else { k3 &= keep; }
-                uint32_t h = word_hash(k0, k1, k2, k3) & T.word_mask;
-                uint32_t hsym = 0;
-                for (;;) {
-                    const uint4 key = T.word_keys[h];
-                    hsym = T.word_syms[h];  // issued with the key: one latency, not two
-                    if (key.x == k0 && key.y == k1 && key.z == k2 && key.w == k3) { done = true; break; }
-                    if (key.x == 0) break;
-                    h = (h + 1) & T.word_mask;
-                }
+                // two-choice cuckoo table: both candidate slots (key and symbol) load together
+                const uint32_t h1 = word_hash(k0, k1, k2, k3) & T.word_mask;
+                const uint32_t h2 = word_hash2(k0, k1, k2, k3) & T.word_mask;
+                const uint4 key1 = T.word_keys[h1], key2 = T.word_keys[h2];
+                const uint32_t sym1 = T.word_syms[h1], sym2 = T.word_syms[h2];
+                const bool hit1 = key1.x == k0 && key1.y == k1 && key1.z == k2 && key1.w == k3;
+                const bool hit2 = key2.x == k0 && key2.y == k1 && key2.z == k2 && key2.w == k3;
+                const uint32_t hsym = hit1 ? sym1 : sym2;
+                done = hit1 || hit2;
                 if (done) {
                     S[ws] = Sym<SymT>::narrow(hsym);
                     M[ws] = (SymT)1;
@@ -575,11 +581,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     const int p0 = left ? 31 - __builtin_clz(left) : 0;
                     const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
                     const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
-                    // issue both first probes
-                    const uint32_t h1 = pair_hash(merged, sr) & T.pair_mask;
-                    const uint32_t h2 = pair_hash(sl, merged) & T.pair_mask;
-                    const uint2 s1 = T.pair_slots[right ? h1 : 0u];  // unconditional loads: no exec juggling
-                    const uint2 s2 = T.pair_slots[left ? h2 : 0u];
+                    // issue the lookups of both new pairs: four independent loads (unconditional: a
+                    // missing neighbour reads as symbol 0, and the result is discarded)
+                    const PairProbe s1 = pair_issue(T, merged, sr);
+                    const PairProbe s2 = pair_issue(T, sl, merged);
                     // rescan what the merge did not touch
                     if (left) cand &= ~(1u << p0);
                     br = 0xFFFFFFFFu;
@@ -594,8 +599,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                         }
                     }
                     // the two new pairs
-                    const uint32_t mr = right ? pair_resolve(T, s1, merged, sr, h1) : SYM_NONE;
-                    const uint32_t ml = left ? pair_resolve(T, s2, sl, merged, h2) : SYM_NONE;
+                    const uint32_t mr = right ? pair_resolve(s1, merged, sr) : SYM_NONE;
+                    const uint32_t ml = left ? pair_resolve(s2, sl, merged) : SYM_NONE;
                     if (right) {
                         const SymT mn = Sym<SymT>::narrow(mr);
                         Mw[p] = mn;

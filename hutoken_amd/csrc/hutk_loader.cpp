@@ -334,16 +334,24 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
         return fail(HUTK_E_UNSUPPORTED, "vocabulary too large for 20-bit symbols");
     T.n_pairs = (int64_t)entries.size();
     {
-        uint32_t cap = pow2_at_least(entries.size() * 2 + 16);
+        // two-choice cuckoo table at load <= 0.4; a placement failure (not seen in practice) doubles it
+        auto left_of = [&](uint32_t i) { return (uint32_t)entries[i] & 0xFFFFFu; };
+        auto right_of = [&](uint32_t i) {
+            return ((uint32_t)entries[i] >> 20) | (((uint32_t)(entries[i] >> 32) & 0xFFu) << 12);
+        };
+        uint32_t cap = pow2_at_least(entries.size() * 5 / 2 + 16);
+        std::vector<uint32_t> where;
+        for (int attempt = 0;; attempt++) {
+            if (cuckoo_place(entries.size(), cap,
+                             [&](uint32_t i) { return pair_hash(left_of(i), right_of(i)); },
+                             [&](uint32_t i) { return pair_hash2(left_of(i), right_of(i)); }, where))
+                break;
+            if (attempt == 4) return fail(HUTK_E_UNSUPPORTED, "pair table could not be built");
+            cap *= 2;
+        }
         T.pair_mask = cap - 1;
         T.pair_slots.assign(cap, SLOT_EMPTY);
-        for (uint64_t en : entries) {
-            const uint32_t w0 = (uint32_t)en, w1 = (uint32_t)(en >> 32);
-            const uint32_t l = w0 & 0xFFFFFu, r = (w0 >> 20) | ((w1 & 0xFFu) << 12);
-            uint32_t h = pair_hash(l, r) & T.pair_mask;
-            while (T.pair_slots[h] != SLOT_EMPTY) h = (h + 1) & T.pair_mask;
-            T.pair_slots[h] = en;
-        }
+        for (size_t i = 0; i < entries.size(); i++) T.pair_slots[where[i]] = entries[i];
     }
 
     // ---- byte-encoder mode: direct table for the initial (byte, byte) pairs ----
@@ -351,13 +359,12 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     if (is_byte_encoder) {
         auto host_lookup = [&](uint32_t l, uint32_t r) -> uint32_t {
             const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
-            uint32_t h = pair_hash(l, r) & T.pair_mask;
-            for (;;) {
+            for (uint32_t h : {pair_hash(l, r) & T.pair_mask, pair_hash2(l, r) & T.pair_mask}) {
                 const uint64_t sl = T.pair_slots[h];
-                if ((uint32_t)sl == 0xFFFFFFFFu) return SYM_NONE;
-                if ((uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1) return (uint32_t)(sl >> 40);
-                h = (h + 1) & T.pair_mask;
+                if (sl != SLOT_EMPTY && (uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1)
+                    return (uint32_t)(sl >> 40);
             }
+            return SYM_NONE;
         };
         if (T.sym16) T.bytepair16.assign(65536, 0xFFFFu); else T.bytepair32.assign(65536, SYM_NONE);
         for (int b1 = 1; b1 < 256; b1++)
