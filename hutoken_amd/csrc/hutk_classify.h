@@ -236,8 +236,10 @@ HUTK_CLS_HD uint32_t classify16(const uint32_t (&d)[8], uint32_t dbits, bool* ex
             int j = 0;
             while (!((todo >> j) & 1u)) j++;
             todo &= todo - 1;
-            const int k = 4 * q + j;  // window byte of the lead, follower at k + 1 <= 24
-            const uint32_t lead = cls_win_byte(d, k), fol = cls_win_byte(d, k + 1);
+            // lead at byte j of dword q, follower right after it (possibly byte 0 of dword q + 1); q is a
+            // compile-time constant here, so no register array is indexed dynamically (scratch)
+            const uint32_t w = j ? funnel_r(d[q + 1], d[q], 8 * j) : d[q];
+            const uint32_t lead = w & 0xFFu, fol = (w >> 8) & 0xFFu;
             const uint64_t set = (lead == 0xC3u) ? HUN_AFTER_C3 : HUN_AFTER_C5;
             if ((set >> (fol & 63u)) & 1ull) h |= 0x80u << (8 * j);
         }

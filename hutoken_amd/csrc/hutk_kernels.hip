@@ -89,6 +89,22 @@ __device__ __forceinline__ int32_t sym_to_id(const DevTables& T, uint32_t s) {
     return s < T.n_sym ? T.sym_id[s] : -1;
 }
 
+// Out of line on purpose: the per-position form indexes its window dynamically (scratch), and inlined that
+// would put a scratch store of the window on the hot path of every tile.
+struct Win8 { uint32_t d[8]; };  // by value: the window travels in registers
+__device__ __noinline__ uint32_t classify16_exact_cold(Win8 w, uint32_t dbits) {
+    return classify16_exact(w.d, dbits);
+}
+
+// One wavefront per workgroup: LDS instructions of a wavefront execute in order, so lanes exchange data
+// through LDS without s_barrier -- and without the "wait for every outstanding global load and STORE"
+// that __syncthreads() implies.  This only stops the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void raise(int32_t* err, int32_t code) { atomicCAS(err, 0, code); }
 
 // ------------------------------------------------------------------------
@@ -249,6 +265,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
 
 template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM>
 __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+    static_assert(TILE_THREADS == 64, "k_tiles is one wavefront per workgroup (wave_sync)");
     __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
     __shared__ uint32_t docm[WINDOW / 32 + 3];
     __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     if (lane == 0) { s_arena_used = 0; s_extra = 0; }
     if (lane < ARENA_WORDS) arena_ws[lane] = 0xFFFFu;
     if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
-    __syncthreads();
+    wave_sync();
 
     // ---- 2. document starts inside the window -------------------------------
     const int64_t dfirst = W.tile_first_doc[tile];
@@ -311,7 +328,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         const int li = (int)(o - gw);
         if (li >= 0) atomicOr(&docm[li >> 5], 1u << (li & 31));
     }
-    __syncthreads();
+    wave_sync();
     HUTK_STAMP(1);
 
     // ---- 3. classification in registers: 32-byte window per lane ------------------
@@ -330,7 +347,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                                 (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
         bool exotic;
         flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
-        if (exotic) flags = classify16_exact(dw, dbits);  // overlong encodings: per-position decode
+        if (exotic) {  // overlong encodings: per-position decode
+            Win8 w8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
+            flags = classify16_exact_cold(w8, dbits);
+        }
     }
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     wmask16[lane] = (uint16_t)flags;
     HUTK_STAMP(2);
 
-    __syncthreads();
+    wave_sync();
     HUTK_STAMP(3);
 
     // ---- 5. words, spread evenly over the lanes: whole-word table; mark what needs merging ----
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             for (uint32_t m = own; m; m &= m - 1, wi++)
                 if (wi < 64u) stage[wi] = (uint16_t)(16 * lane + __builtin_ctz(m));
         }
-        __syncthreads();
+        wave_sync();
         if (r0 + lane < nW) {
             const int ws = stage[lane];
             // end of the word: the next start bit within 63 positions (bits beyond the
@@ -470,7 +492,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
             if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
         }
-        __syncthreads();
+        wave_sync();
     }
     HUTK_STAMP(4);
 
@@ -489,7 +511,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 for (uint32_t m = mown; m; m &= m - 1, mi++)
                     if (mi < 64u) stage[mi] = (uint16_t)(16 * lane + __builtin_ctz(m));
             }
-            __syncthreads();
+            wave_sync();
             bool have = r0 + lane < nM;
             const int ws = have ? stage[lane] : 0;
             SymT* Sw = S + ws;
@@ -629,7 +651,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     }
                 }
             }
-            __syncthreads();
+            wave_sync();
         }
     }
     HUTK_STAMP(5);
@@ -718,7 +740,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(base[__builtin_ctz(sv)]));
         }
     }
-    __syncthreads();
+    wave_sync();
     HUTK_STAMP(7);
 
     // ---- 8. ids emitted before each document that starts in this tile ----------
