@@ -64,7 +64,7 @@ struct hutk_ctx {
     // device tables
     DevBuf<uint64_t> d_pair, d_char;
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
-    DevBuf<uint32_t> d_item_sym, d_prefix_syms;
+    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
     DevBuf<uint8_t> d_item_direct;
     DevBuf<uint16_t> d_bytepair16;
     DevBuf<uint4> d_word_keys;
@@ -76,7 +76,8 @@ struct hutk_ctx {
     DevTables dt{};
 
     // workspace
-    DevBuf<int32_t> w_run, w_exc_tok;
+    DevBuf<uint32_t> w_run;
+    DevBuf<int32_t> w_exc_tok;
     DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
@@ -130,6 +131,7 @@ int upload_tables(hutk_ctx* c) {
     D.n_prefix = (int32_t)T.prefix_syms.size();
     D.prefix_alone_ids = c->d_prefix_alone.p;
     D.n_prefix_alone = 0;
+    D.prefix_alone_syms = nullptr;
     D.is_byte_encoder = T.is_byte_encoder;
     D.has_prefix = T.has_prefix;
     D.rank_is_sym = T.rank_is_sym;
@@ -145,7 +147,7 @@ int upload_tables(hutk_ctx* c) {
     if (T.has_prefix && !T.prefix_alone_syms.empty()) {
         if (T.prefix_alone_syms.size() > (size_t)EXC_LDS_UNITS)
             return set_err(HUTK_E_UNSUPPORTED, "prefix too long");
-        DevBuf<uint32_t> d_syms;
+        DevBuf<uint32_t>& d_syms = c->d_prefix_alone_syms;  // in: units; out: the merged symbols
         DevBuf<int32_t> d_n;
         HIP_TRY(d_syms.reserve(T.prefix_alone_syms.size()));
         HIP_TRY(d_n.reserve(1));
@@ -157,7 +159,7 @@ int upload_tables(hutk_ctx* c) {
         int32_t n = 0;
         HIP_TRY(hipMemcpy(&n, d_n.p, 4, hipMemcpyDeviceToHost));
         D.n_prefix_alone = n;
-        d_syms.release();
+        D.prefix_alone_syms = d_syms.p;
         d_n.release();
     }
     return HUTK_OK;
@@ -214,7 +216,7 @@ void destroy(hutk_ctx* c) {
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
-        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_item_direct.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->d_word_keys.release(); c->d_word_syms.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
@@ -451,7 +453,7 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     launch_exceptions(c->dt, A, W, s);
     launch_scan(A, W, s);
-    launch_gather(A, W, s);
+    launch_gather(c->dt, A, W, s);
     launch_doc_offsets(A, W, s);
     HIP_TRY(hipGetLastError());
     if (c->timing) {

@@ -40,7 +40,8 @@ struct DevTables {
     uint32_t char_mask, char_shift;
     const uint32_t* prefix_syms;
     int32_t n_prefix;
-    const int32_t* prefix_alone_ids;
+    const int32_t* prefix_alone_ids;      // the prefix encoded as a word of its own: ids ...
+    const uint32_t* prefix_alone_syms;    // ... and the same tokens as symbols
     int32_t n_prefix_alone;
     int32_t is_byte_encoder, has_prefix, rank_is_sym, ident_ids;
     // byte-encoder mode: merged symbol of the initial pair (byte b1, byte b2) at
@@ -67,7 +68,7 @@ struct ExcRec {
 };
 
 struct Workspace {
-    int32_t* run;         // [cap_bytes] dense id run of tile t at run[t*TILE_BYTES + first_word + k]
+    uint32_t* run;        // SYMBOLS of tile t's lane-path words at run[t*RUN_STRIDE + first_word + k]; k_gather maps to ids
     int32_t* exc_tok;     // [cap_bytes + pad] ids of exception words at their own byte offset (+ doc padding)
     uint32_t* exc_sym;    // [cap_bytes + pad] symbol array of exception words too long for LDS
     uint32_t* exc_mrg;    // [cap_bytes + pad] their pair array
@@ -103,10 +104,10 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
-void launch_gather(const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s);
 // one-off at context creation: merge a symbol sequence on the device, return ids
-void launch_bpe_symbols(const DevTables& t, const uint32_t* d_syms, int n, int32_t* d_ids_out,
+void launch_bpe_symbols(const DevTables& t, uint32_t* d_syms, int n, int32_t* d_ids_out,
                         int32_t* d_n_out, hipStream_t s);
 
 }  // namespace hutk

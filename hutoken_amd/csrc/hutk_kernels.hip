@@ -706,7 +706,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    int32_t* run_out = W.run + tile * RUN_STRIDE + run_start;
+    uint32_t* run_out = W.run + tile * RUN_STRIDE + run_start;  // symbols; k_gather turns them into ids
     for (uint32_t m = own; m; m &= m - 1) {
         const int ws = 16 * lane + __builtin_ctz(m);
         bool is_exc;
@@ -735,9 +735,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         } else {
             const uint32_t na = alone_ids(ws);
             run += (uint32_t)__popc(sv) + na;
-            for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_ids[i];
-            for (; sv; sv &= sv - 1)  // surviving units, left to right
-                run_out[pos++] = sym_to_id(T, Sym<SymT>::widen(base[__builtin_ctz(sv)]));
+            for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_syms[i];
+            for (; sv; sv &= sv - 1)  // surviving units, left to right (stores only: nothing here waits)
+                run_out[pos++] = Sym<SymT>::widen(base[__builtin_ctz(sv)]);
         }
     }
     wave_sync();
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
 }
 
 // one-off: merge a short symbol sequence (the prefix encoded as its own word)
-__global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, const uint32_t* syms, int n, int32_t* ids_out,
+__global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, uint32_t* syms, int n, int32_t* ids_out,
                                                      int32_t* n_out) {
     __shared__ uint32_t Sl[EXC_LDS_UNITS];
     __shared__ uint32_t Ml[EXC_LDS_UNITS];
@@ -1012,7 +1012,10 @@ __global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, const uint32_t*
     for (int i = lane; i < n; i += 64) Sl[i] = syms[i];
     __syncthreads();
     const int64_t left = bpe_wave(T, LdsArr{Sl}, LdsArr{Ml}, n, lane);
-    for (int i = lane; i < left; i += 64) ids_out[i] = sym_to_id(T, Sl[i]);
+    for (int i = lane; i < left; i += 64) {
+        ids_out[i] = sym_to_id(T, Sl[i]);
+        syms[i] = Sl[i];
+    }
     if (lane == 0) *n_out = (int32_t)left;
 }
 
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(BatchArgs A, Worksp
 constexpr int GATHER_EXC_LDS = 1024;  // >= TILE_BYTES: at most one exception word per byte
 
 constexpr int GATHER_THREADS = 64;
-__global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     const int tid = threadIdx.x;
@@ -1099,13 +1102,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspac
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
     const uint32_t nexc = W.tile_nexc[tile];
-    const int32_t* run = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
+    const uint32_t* run = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
     if (base + (int64_t)W.tile_count[tile] > A.ids_cap) {
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
         return;
     }
     if (nexc == 0) {
-        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = run[k];
+        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = sym_to_id(T, run[k]);
         return;
     }
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
@@ -1127,7 +1130,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(BatchArgs A, Workspac
             const uint32_t mid = (lo + hi) >> 1;
             if (e_pos[mid] <= k) lo = mid + 1; else hi = mid;
         }
-        A.ids_out[base + k + e_cum[lo]] = run[k];
+        A.ids_out[base + k + e_cum[lo]] = sym_to_id(T, run[k]);
     }
     for (uint32_t e = 0; e < nexc; e++) {
         const ExcRec r = recs[e];
@@ -1194,14 +1197,14 @@ void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(1024), 0, s, a, w, nb);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
 }
-void launch_gather(const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(GATHER_THREADS), 0, s, a, w);
+void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(GATHER_THREADS), 0, s, t, a, w);
 }
 void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const unsigned g = (unsigned)((a.n_docs + 1 + 255) / 256);
     hipLaunchKernelGGL(k_doc_off, dim3(g), dim3(256), 0, s, a, w);
 }
-void launch_bpe_symbols(const DevTables& t, const uint32_t* d_syms, int n, int32_t* d_ids_out,
+void launch_bpe_symbols(const DevTables& t, uint32_t* d_syms, int n, int32_t* d_ids_out,
                         int32_t* d_n_out, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_symbols, dim3(1), dim3(64), 0, s, t, d_syms, n, d_ids_out, d_n_out);
 }
