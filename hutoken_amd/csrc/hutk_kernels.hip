@@ -59,9 +59,9 @@ __device__ __forceinline__ uint32_t pair_resolve(const PairProbe& p, uint32_t l,
     const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
     // an empty slot is all ones, which is also the key pattern of (SYM_UNK, SYM_UNK): its merged field
     // then reads 0xFFFFFF, which no entry has
-    uint32_t y = 0xFFFFFFFFu;
-    if (p.a.x == k0 && (p.a.y & 0xFFu) == k1) y = p.a.y;
-    if (p.b.x == k0 && (p.b.y & 0xFFu) == k1) y = p.b.y;
+    // (bitwise on purpose: with && the compiler loads .x first and .y only on a match -- a second round trip)
+    const uint32_t da = (p.a.x ^ k0) | ((p.a.y ^ k1) & 0xFFu), db = (p.b.x ^ k0) | ((p.b.y ^ k1) & 0xFFu);
+    const uint32_t y = da == 0 ? p.a.y : db == 0 ? p.b.y : 0xFFFFFFFFu;
     return y == 0xFFFFFFFFu ? SYM_NONE : y >> 8;
 }
 __device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, uint32_t r) {
@@ -426,8 +426,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 const uint32_t h2 = word_hash2(k0, k1, k2, k3) & T.word_mask;
                 const uint4 key1 = T.word_keys[h1], key2 = T.word_keys[h2];
                 const uint32_t sym1 = T.word_syms[h1], sym2 = T.word_syms[h2];
-                const bool hit1 = key1.x == k0 && key1.y == k1 && key1.z == k2 && key1.w == k3;
-                const bool hit2 = key2.x == k0 && key2.y == k1 && key2.z == k2 && key2.w == k3;
+                // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
+                const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
+                const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
                 const uint32_t hsym = hit1 ? sym1 : sym2;
                 done = hit1 || hit2;
                 if (done) {
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             int n = 0;
             SymT* Sdst = S + ws;
             int slot = -1;
-            if (!exc && pfx) {
+            if (!BYTE_MODE && !exc && pfx) {
                 slot = (int)atomicAdd(&s_arena_used, 1u);
                 if (slot >= ARENA_WORDS ||
                     atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 if (n > LANE_MAX_UNITS) exc = true;
             }
             if (done) {
-            } else if (!exc && pfx) {  // arena word: always at least two units, always through the merge loop
+            } else if (!BYTE_MODE && !exc && pfx) {  // arena word: always at least two units, always through the merge loop
                 arena_ws[slot] = (uint16_t)ws;
                 arena_n[slot] = (uint16_t)n;
             } else if (exc) {
