@@ -291,6 +291,26 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (RANK_IS_SYM) return merged;
         return (uint32_t)T.sym_id[merged] ^ 0x80000000u;  // signed id order as unsigned
     };
+    // best (lowest rank, leftmost) among the candidate pairs `cand` of a word whose pair results are at Mw[].
+    // Four candidates per step: their LDS reads are independent, so a step costs one LDS latency, not four.
+    // Strict "<" keeps the leftmost pair of equal rank (queue.c:162-164); a step that runs out of
+    // candidates repeats its first one, which cannot win against itself.
+    auto scan_best = [&](uint32_t c, const SymT* Mw, uint32_t& br, int& bp, SymT& bm) {
+        while (c) {
+            const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
+            const int i0 = __builtin_ctz(c);
+            const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
+                      i3 = c3 ? __builtin_ctz(c3) : i0;
+            const SymT m0 = Mw[i0], m1 = Mw[i1], m2 = Mw[i2], m3 = Mw[i3];
+            const uint32_t r0 = RK(Sym<SymT>::widen(m0)), r1 = RK(Sym<SymT>::widen(m1)),
+                           r2 = RK(Sym<SymT>::widen(m2)), r3 = RK(Sym<SymT>::widen(m3));
+            if (r0 < br) { br = r0; bp = i0; bm = m0; }
+            if (r1 < br) { br = r1; bp = i1; bm = m1; }
+            if (r2 < br) { br = r2; bp = i2; bm = m2; }
+            if (r3 < br) { br = r3; bp = i3; bm = m3; }
+            c = c3 & (c3 - 1);
+        }
+    };
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
     const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
@@ -570,16 +590,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                         if (m != SYM_NONE) cand |= 1u << i;
                     }
                 }
-                for (uint32_t c = cand; c; c &= c - 1) {
-                    const int i = __builtin_ctz(c);
-                    const SymT mv = Mw[i];
-                    const uint32_t r = RK(Sym<SymT>::widen(mv));
-                    if (r < br) {  // strict: the leftmost pair of equal rank wins (queue.c:162-164)
-                        br = r;
-                        bp = i;
-                        bm = mv;
-                    }
-                }
+                scan_best(cand, Mw, br, bp, bm);
             }
             for (;;) {
                 if (have && cand == 0) {
@@ -611,16 +622,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                     // rescan what the merge did not touch
                     if (left) cand &= ~(1u << p0);
                     br = 0xFFFFFFFFu;
-                    for (uint32_t c = cand; c; c &= c - 1) {
-                        const int i = __builtin_ctz(c);
-                        const SymT mv = Mw[i];
-                        const uint32_t r = RK(Sym<SymT>::widen(mv));
-                        if (r < br) {
-                            br = r;
-                            bp = i;
-                            bm = mv;
-                        }
-                    }
+                    scan_best(cand, Mw, br, bp, bm);
                     // the two new pairs
                     const uint32_t mr = right ? pair_resolve(s1, merged, sr) : SYM_NONE;
                     const uint32_t ml = left ? pair_resolve(s2, sl, merged) : SYM_NONE;
