@@ -66,11 +66,11 @@ struct hutk_ctx {
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
     DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
     DevBuf<uint8_t> d_item_direct;
-    DevBuf<uint16_t> d_bytepair16;
+    DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<uint4> d_word_keys;
     DevBuf<uint32_t> d_word_syms;
     int64_t n_word_entries = 0;
-    DevBuf<uint32_t> d_bytepair32;
+    DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
     DevBuf<long long> w_prof;
     bool profile = false;
     DevTables dt{};
@@ -107,8 +107,25 @@ int upload_tables(hutk_ctx* c) {
     UP(c->d_char, T.char_slots);
     UP(c->d_sym_id, T.sym_id);
     UP(c->d_prefix_syms, T.prefix_syms);
-    UP(c->d_bytepair16, T.bytepair16);
-    UP(c->d_bytepair32, T.bytepair32);
+    // byte-encoder mode: (first byte, second byte) -> {symbol of the first byte, merged symbol of the pair}
+    // in one entry, so the merge loop's set-up is one load per unit (second byte 0 = "no next unit")
+    std::vector<uint32_t> bp16;
+    std::vector<uint64_t> bp32;
+    if (T.is_byte_encoder) {
+        if (T.sym16) {
+            bp16.assign(65536, 0xFFFFFFFFu);
+            for (uint32_t b1 = 0; b1 < 256; b1++)
+                for (uint32_t b2 = 0; b2 < 256; b2++)
+                    bp16[(b1 << 8) | b2] = (T.item_sym[b1] & 0xFFFFu) | ((uint32_t)T.bytepair16[(b1 << 8) | b2] << 16);
+        } else {
+            bp32.assign(65536, ~0ull);
+            for (uint32_t b1 = 0; b1 < 256; b1++)
+                for (uint32_t b2 = 0; b2 < 256; b2++)
+                    bp32[(b1 << 8) | b2] = (uint64_t)T.item_sym[b1] | ((uint64_t)T.bytepair32[(b1 << 8) | b2] << 32);
+        }
+    }
+    UP(c->d_bytepair16, bp16);
+    UP(c->d_bytepair32, bp32);
 #undef UP
     HIP_TRY(c->d_item_sym.reserve(256));
     HIP_TRY(hipMemcpy(c->d_item_sym.p, T.item_sym, sizeof T.item_sym, hipMemcpyHostToDevice));

@@ -201,11 +201,17 @@ template <> struct Sym<uint32_t> {
     static __device__ __forceinline__ uint32_t narrow(uint32_t v) { return v; }
     static __device__ __forceinline__ uint32_t widen(uint32_t v) { return v; }
     static constexpr uint32_t NONE = SYM_NONE;
+    typedef uint2 Pair;  // entry of the (byte, next byte) table: {symbol of the byte, merged symbol}
+    static __device__ __forceinline__ uint32_t pair_sym(uint2 e) { return e.x; }
+    static __device__ __forceinline__ uint32_t pair_merged(uint2 e) { return e.y; }
 };
 template <> struct Sym<uint16_t> {
     static __device__ __forceinline__ uint16_t narrow(uint32_t v) { return (uint16_t)v; }
     static __device__ __forceinline__ uint32_t widen(uint16_t v) { return (uint32_t)v; }
     static constexpr uint16_t NONE = 0xFFFFu;
+    typedef uint32_t Pair;
+    static __device__ __forceinline__ uint16_t pair_sym(uint32_t e) { return (uint16_t)e; }
+    static __device__ __forceinline__ uint16_t pair_merged(uint32_t e) { return (uint16_t)(e >> 16); }
 };
 
 // 64 bits of a bitmap starting at bit `start` (the bitmap has 2 words of slack)
@@ -236,7 +242,6 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // word that starts in the tile may end).  Lane l owns positions 16l .. 16l+15.
 // No workgroup barriers: a long word delays only its own wavefront.
 // ------------------------------------------------------------------------
-constexpr uint32_t EXC_MARK = 0x8000u;  // M[word start] of an exception word
 constexpr int N_PHASE = 10;
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
@@ -270,18 +275,20 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     __shared__ uint32_t docm[WINDOW / 32 + 3];
     __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
     __shared__ __attribute__((aligned(8))) uint32_t mergem[NPOS / 32 + 2];  // positions whose word needs the merge loop
-    __shared__ uint16_t stage[64];                                      // word starts handed to the lanes, 64 at a time
-    __shared__ __attribute__((aligned(16))) SymT S[NPOS];
-    __shared__ __attribute__((aligned(16))) SymT M[NPOS];
+    __shared__ uint16_t stage[64];  // word starts handed to the lanes, 64 at a time; the epilogue's lane prefix later
+    __shared__ __attribute__((aligned(8))) uint32_t excm[NPOS / 32 + 2];   // starts of exception words
+    __shared__ __attribute__((aligned(8))) uint32_t livem[NPOS / 32 + 2];  // surviving units (see phase 5)
+    __shared__ __attribute__((aligned(16))) SymT S[NPOS];   // symbol of unit i of the word at ws: S[ws + i]
+    constexpr int MARENA = 512;                             // pair results of one round of merge-loop words
+    __shared__ __attribute__((aligned(16))) SymT Mar[MARENA];
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
-    __shared__ uint16_t lanepref[64];  // ids before lane l's positions
     // non-byte mode with a prefix: the first word of a document gets the prefix units in front of its own,
-    // which does not fit its byte span; up to ARENA_WORDS such words per tile merge in this side arena
-    // (more than that: exception path)
+    // which does not fit its byte span; up to ARENA_WORDS such words per tile keep their units in this side
+    // arena (more than that: exception path)
     constexpr int ARENA_WORDS = 4, ARENA_W = LANE_MAX_UNITS + 4;
     __shared__ SymT arenaS[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
-    __shared__ SymT arenaM[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
+    __shared__ uint32_t arena_live[ARENA_WORDS];  // their surviving units
     __shared__ uint16_t arena_ws[ARENA_WORDS], arena_n[ARENA_WORDS];
     __shared__ uint32_t s_arena_used, s_extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
 
@@ -334,9 +341,9 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             s_item_direct[i] = T.item_direct[i];
         }
     if (lane < WINDOW / 32 + 3) docm[lane] = 0;
-    if (lane < NPOS / 32 + 2) mergem[lane] = 0;
+    if (lane < NPOS / 32 + 2) { mergem[lane] = 0; excm[lane] = 0; livem[lane] = 0; }
     if (lane == 0) { s_arena_used = 0; s_extra = 0; }
-    if (lane < ARENA_WORDS) arena_ws[lane] = 0xFFFFu;
+    if (lane < ARENA_WORDS) { arena_ws[lane] = 0xFFFFu; arena_live[lane] = 0; }
     if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
     wave_sync();
 
@@ -389,6 +396,12 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
     // Word j of the tile goes to lane j % 64: every round the owning lanes put the starts of words
     // [r0, r0 + 64) into a 64-entry staging buffer (no per-tile word list is kept in LDS: its
     // footprint would cost resident wavefronts, and residency is what hides the gather latency).
+    //
+    // State handed to the epilogue, all of it bitmaps over tile positions:
+    //   livem  units that survive: starts as "every word start" (the first unit of a word always
+    //          survives); the merge loop adds the other survivors of its words (unit i of the word at ws
+    //          is bit ws + i, and S[ws + i] its symbol); exception and arena words are taken out
+    //   excm   starts of exception words
     const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
     uint32_t own = flags;                    // starts that are words of this tile
     {
@@ -396,6 +409,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (lo >= limit) own = 0;
         else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
     }
+    reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
     uint32_t nW;
     const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
     for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
@@ -413,21 +427,26 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
             const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
             const bool docfirst = bit_at(docm, ws + LOOKBACK);
+            const uint32_t b0 = sb[ws + LOOKBACK];
             // first word of a document with a prefix configured (core.c:364-366, 421-451): a leading space
             // means "prefix ids as a word of their own, then the word as it is" (handled in the epilogue);
             // otherwise the prefix units go in front of the word's own units (arena)
-            const bool pfx = T.has_prefix && docfirst && sb[ws + LOOKBACK] != ' ';
+            const bool pfx = T.has_prefix && docfirst && b0 != ' ';
             bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
             if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
                 exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
-            bool done = false;
-            if (!exc && !pfx && T.word_mask && nb >= 2 && nb <= 16) {
-                // whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single
-                // token it encodes to.  Entries were verified by this pipeline at context creation.
+            // Every global load of this round is issued here, unconditionally and together, so that the round
+            // costs one memory round trip whatever mix of words the lanes hold:
+            //   byte mode: symbol of the first byte (all a one-byte word needs)
+            //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
+            //   encodes to; two-choice cuckoo table, entries verified by this pipeline at context creation
+            const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
+            uint32_t k0, k1, k2, k3;
+            {
                 const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
                 const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
                 const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
-                uint32_t k0 = q0, k1 = q1, k2 = q2, k3 = q3;
+                k0 = q0; k1 = q1; k2 = q2; k3 = q3;
                 if (o8) {
                     k0 = funnel_r(q1, q0, o8);
                     k1 = funnel_r(q2, q1, o8);
@@ -440,21 +459,26 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
                 else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
                 else if (full == 2) { k2 &= keep; k3 = 0; }
-                else { k3 &= keep; }
-                // two-choice cuckoo table: both candidate slots (key and symbol) load together
-                const uint32_t h1 = word_hash(k0, k1, k2, k3) & T.word_mask;
-                const uint32_t h2 = word_hash2(k0, k1, k2, k3) & T.word_mask;
-                const uint4 key1 = T.word_keys[h1], key2 = T.word_keys[h2];
-                const uint32_t sym1 = T.word_syms[h1], sym2 = T.word_syms[h2];
+                else if (full == 3) { k3 &= keep; }
+            }
+            const uint32_t h1 = probe ? word_hash(k0, k1, k2, k3) & T.word_mask : 0u;
+            const uint32_t h2 = probe ? word_hash2(k0, k1, k2, k3) & T.word_mask : 0u;
+            uint4 key1 = make_uint4(0, 0, 0, 0), key2 = key1;
+            uint32_t sym1 = 0, sym2 = 0, isym = 0;
+            if (T.word_mask) {  // uniform
+                key1 = T.word_keys[h1];
+                key2 = T.word_keys[h2];
+                sym1 = T.word_syms[h1];
+                sym2 = T.word_syms[h2];
+            }
+            if (BYTE_MODE) isym = T.item_sym[b0];
+            bool done = false;
+            if (probe) {
                 // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
                 const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
                 const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
-                const uint32_t hsym = hit1 ? sym1 : sym2;
                 done = hit1 || hit2;
-                if (done) {
-                    S[ws] = Sym<SymT>::narrow(hsym);
-                    M[ws] = (SymT)1;
-                }
+                if (done) S[ws] = Sym<SymT>::narrow(hit1 ? sym1 : sym2);
             }
             int n = 0;
             SymT* Sdst = S + ws;
@@ -500,15 +524,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 if (n > LANE_MAX_UNITS) exc = true;
             }
             if (done) {
-            } else if (!BYTE_MODE && !exc && pfx) {  // arena word: always at least two units, always through the merge loop
+            } else if (!BYTE_MODE && !exc && pfx) {  // arena word: at least two units, always through the merge loop
                 arena_ws[slot] = (uint16_t)ws;
                 arena_n[slot] = (uint16_t)n;
+                atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));  // its ids are counted from arena_live[]
             } else if (exc) {
-                M[ws] = (SymT)EXC_MARK;
+                atomicOr(&excm[ws >> 5], 1u << (ws & 31));
+                atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));
                 done = true;
             } else if (n == 1) {  // a single unit: nothing to merge
-                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(T.item_sym[sb[ws + LOOKBACK]]);
-                M[ws] = (SymT)1;
+                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(isym);
                 done = true;
             }
             if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
@@ -519,14 +544,16 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
 
     // ---- 6. merge: ONE LANE PER WORD, one merge step per trip ------------------------
     // Each lane keeps (br, bp, bm) = rank, position and merged symbol of its word's best pair.
-    // A step applies that merge, ISSUES the two pair-table loads for the new neighbour pairs,
+    // A step applies that merge, ISSUES the pair-table loads for the two new neighbour pairs,
     // rescans the untouched candidates in LDS while those loads are in flight, and then
     // picks the next best among {rescan, new left pair, new right pair}.
+    // Pair results live in a small arena (Mar) handed out per round: only about one word in ten gets here,
+    // and a position-indexed array for them would cost a quarter of the resident wavefronts.
     {
         const uint32_t mown = reinterpret_cast<const uint16_t*>(mergem)[lane];
         uint32_t nM;
         const uint32_t mbase = wave_excl_scan(__popc(mown), lane, &nM);
-        for (uint32_t r0 = 0; r0 < nM; r0 += 64) {
+        for (uint32_t r0 = 0; r0 < nM;) {
             {
                 uint32_t mi = mbase - r0;
                 for (uint32_t m = mown; m; m &= m - 1, mi++)
@@ -536,50 +563,55 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             bool have = r0 + lane < nM;
             const int ws = have ? stage[lane] : 0;
             SymT* Sw = S + ws;
-            SymT* Mw = M + ws;
-            int n_arena = 0;
-            if (!BYTE_MODE && have)
-                for (int a = 0; a < ARENA_WORDS; a++)
-                    if (arena_ws[a] == ws) {
-                        Sw = arenaS + a * ARENA_W;
-                        Mw = arenaM + a * ARENA_W;
-                        n_arena = arena_n[a];
-                    }
+            int arena_slot = -1;
+            int n = 0, nb = 0;
+            if (have) {
+                nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
+                n = nb;
+                if (!BYTE_MODE) {  // units = characters = lead bytes (+ the prefix units of an arena word)
+                    n = 0;
+                    for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
+                    for (int a = 0; a < ARENA_WORDS; a++)
+                        if (arena_ws[a] == ws) {
+                            Sw = arenaS + a * ARENA_W;
+                            n = arena_n[a];
+                            arena_slot = a;
+                        }
+                }
+            }
+            // arena space for this round: the first k words whose pair results fit (n <= 32, so k >= 16)
+            const uint32_t need = have ? (uint32_t)((n + 7) & ~7) : 0u;
+            uint32_t need_total;
+            const uint32_t moff = wave_excl_scan(need, lane, &need_total);
+            have = have && moff + need <= (uint32_t)MARENA;
+            const uint32_t k_round = (uint32_t)__popcll(__ballot(have));
+            SymT* Mw = Mar + (have ? moff : 0u);
             uint32_t live = 0, cand = 0;  // lane words have at most 32 units
             uint32_t br = 0xFFFFFFFFu;
             int bp = 0;
             SymT bm = 0;
             if (have) {
-                const int nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
-                int n = nb;
-                if (!BYTE_MODE) {  // units = characters = lead bytes (+ the prefix units of an arena word)
-                    n = 0;
-                    for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
-                    if (n_arena) n = n_arena;
-                }
                 live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
                 if (BYTE_MODE) {
-                    // symbols (byte -> symbol LUT) and initial pair results (65536-entry byte-pair table) of
-                    // THIS word only: ~11 % of the words get here, the rest never touch these tables
-                    const SymT* bp = reinterpret_cast<const SymT*>(T.bytepair);
+                    // symbols and initial pair results of THIS word only, one load per unit from the
+                    // 65536-entry (byte, next byte) table: ~11 % of the words get here
                     const uint8_t* wb = sb + ws + LOOKBACK;
-                    for (int i0 = 0; i0 < n; i0 += 8) {
-                        uint32_t sv[8];
-                        SymT mv[8];
+                    for (int i0 = 0; i0 < n; i0 += 16) {
+                        typename Sym<SymT>::Pair e[16];
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {  // 16 independent loads in flight
+                        for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
                             const int i = i0 + j;
                             const uint32_t b = (i < n) ? wb[i] : 0u, b2 = (i + 1 < n) ? wb[i + 1] : 0u;
-                            sv[j] = T.item_sym[b];
-                            mv[j] = bp[(b << 8) | b2];
+                            e[j] = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair)[(b << 8) | b2];
                         }
 #pragma unroll
-                        for (int j = 0; j < 8; j++) {
+                        for (int j = 0; j < 16; j++) {
                             const int i = i0 + j;
                             if (i < n) {
-                                Sw[i] = Sym<SymT>::narrow(sv[j]);
-                                Mw[i] = mv[j];
-                                if (i + 1 < n && mv[j] != Sym<SymT>::NONE) cand |= 1u << i;
+                                const SymT mv = Sym<SymT>::pair_merged(e[j]);
+                                Sw[i] = Sym<SymT>::pair_sym(e[j]);
+                                Mw[i] = mv;
+                                if (i + 1 < n && mv != Sym<SymT>::NONE) cand |= 1u << i;
                             }
                         }
                     }
@@ -594,9 +626,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             }
             for (;;) {
                 if (have && cand == 0) {
-                    // done: park the mask of surviving units (n >= 2 here, so Mw[1] is this word's own)
-                    Mw[0] = (SymT)(live & 0xFFFFu);
-                    Mw[1] = (SymT)(live >> 16);
+                    // done: publish the surviving units (unit 0 always survives and is already in livem)
+                    if (!BYTE_MODE && arena_slot >= 0) {
+                        arena_live[arena_slot] = live;
+                    } else {
+                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                        if ((uint32_t)lm) atomicOr(&livem[ws >> 5], (uint32_t)lm);
+                        if ((uint32_t)(lm >> 32)) atomicOr(&livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                    }
                     have = false;
                 }
                 if (!__any(have)) break;
@@ -655,92 +692,97 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
                 }
             }
             wave_sync();
+            r0 += k_round;
         }
     }
     HUTK_STAMP(5);
 
-    // ---- 7. per-position epilogue: counts -> scan -> ids out, exception records ----
-    // M[word start] now holds: EXC_MARK (exception word), 1 (single unit / whole-word hit), or -- for the
-    // words of the merge loop (mergem bit) -- the low half of the survivor mask (high half in the next slot)
-    auto survivors = [&](int ws, bool* is_exc, const SymT** base) -> uint32_t {
-        *base = S + ws;
-        *is_exc = false;
-        if (!BYTE_MODE)
-            for (int a = 0; a < ARENA_WORDS; a++)
-                if (arena_ws[a] == ws) {
-                    *base = arenaS + a * ARENA_W;
-                    return (uint32_t)arenaM[a * ARENA_W] | ((uint32_t)arenaM[a * ARENA_W + 1] << 16);
-                }
-        const uint32_t lo = M[ws];
-        if ((mergem[ws >> 5] >> (ws & 31)) & 1u) return lo | ((uint32_t)M[ws + 1] << 16);
-        *is_exc = lo == EXC_MARK;
-        return *is_exc ? 0u : 1u;
-    };
-    // ids of the prefix encoded as a word of its own, emitted before a document-first word that starts
-    // with a space (core.c:421-446)
-    auto alone_ids = [&](int ws) -> uint32_t {
-        if (BYTE_MODE || !T.has_prefix) return 0u;
+    // ---- 7. per-position epilogue: counts -> scan -> symbols out, exception records ----
+    // A lane's ids are the surviving units at ITS 16 positions (whichever word they belong to: units sit
+    // inside their word's byte span, so position order is id order), plus -- non-byte mode with a prefix
+    // only -- the ids of arena words and the prefix-alone ids, both counted at their word's start.
+    uint16_t* lanepref = stage;  // the staging buffer is free now: ids before lane l's positions
+    const uint32_t live16 = reinterpret_cast<const uint16_t*>(livem)[lane];
+    const uint32_t exc16 = reinterpret_cast<const uint16_t*>(excm)[lane];
+    constexpr bool PREFIXED = !BYTE_MODE;  // arena words and prefix-alone ids exist in this mode only
+    auto alone_ids = [&](int ws) -> uint32_t {  // prefix encoded as a word of its own (core.c:421-446)
+        if (!PREFIXED || !T.has_prefix) return 0u;
         return (bit_at(docm, ws + LOOKBACK) && sb[ws + LOOKBACK] == ' ') ? (uint32_t)T.n_prefix_alone : 0u;
     };
-    uint32_t mine = 0;  // low 16: ids, high 16: exception words
-    for (uint32_t m = own; m; m &= m - 1) {
-        bool is_exc;
-        const SymT* base;
-        const int ws = 16 * lane + __builtin_ctz(m);
-        const uint32_t sv = survivors(ws, &is_exc, &base);
-        mine += is_exc ? 0x10000u : ((uint32_t)__popc(sv) + alone_ids(ws));
-    }
+    auto arena_at = [&](int ws) -> int {
+        if (PREFIXED)
+            for (int a = 0; a < ARENA_WORDS; a++)
+                if (arena_ws[a] == ws) return a;
+        return -1;
+    };
+    // extra ids (arena words, prefix-alone) of word starts in `starts` (bits of lane lr's 16 positions)
+    auto extra_ids = [&](int lr, uint32_t starts) -> uint32_t {
+        uint32_t x = 0;
+        if (PREFIXED && T.has_prefix)
+            for (uint32_t m = starts; m; m &= m - 1) {
+                const int ws = 16 * lr + __builtin_ctz(m);
+                if (!bit_at(docm, ws + LOOKBACK) || bit_at(excm, ws)) continue;
+                const int a = arena_at(ws);
+                x += a >= 0 ? (uint32_t)__popc(arena_live[a]) : alone_ids(ws);
+            }
+        return x;
+    };
+    uint32_t mine = (uint32_t)__popc(live16) + extra_ids(lane, own) + ((uint32_t)__popc(exc16) << 16);
     uint32_t total;
-    uint32_t run = wave_excl_scan(mine, lane, &total);
-    lanepref[lane] = (uint16_t)run;  // ids before this lane's words
+    uint32_t run = wave_excl_scan(mine, lane, &total);  // low 16: ids, high 16: exception words before me
+    lanepref[lane] = (uint16_t)run;
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
-    const unsigned long long has_words = __ballot(own != 0);
-    const int first_lane = has_words ? __builtin_ctzll(has_words) : 0;
-    const uint32_t first_flags = __shfl(own, first_lane, 64);
-    const uint32_t run_start = has_words ? (uint32_t)(16 * first_lane + __builtin_ctz(first_flags)) : 0u;
     uint32_t exc_first = 0;
     if (lane == 0) {
         if (n_exc) exc_first = atomicAdd(&W.counters[0], n_exc);
         W.tile_count[tile] = n_dense;
         W.tile_dense[tile] = n_dense;
-        W.tile_run_start[tile] = run_start;
+        W.tile_run_start[tile] = 0;
         W.tile_exc_first[tile] = exc_first;
         W.tile_nexc[tile] = n_exc;
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    uint32_t* run_out = W.run + tile * RUN_STRIDE + run_start;  // symbols; k_gather turns them into ids
-    for (uint32_t m = own; m; m &= m - 1) {
-        const int ws = 16 * lane + __builtin_ctz(m);
-        bool is_exc;
-        const SymT* base;
-        uint32_t sv = survivors(ws, &is_exc, &base);
-        uint32_t pos = run & 0xFFFFu;
-        if (is_exc) {
-            const uint64_t slot = (uint64_t)exc_first + (run >> 16);
-            if ((int64_t)slot < W.cap_exc) {
-                const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-                const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-                const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
-                ExcRec rec;
-                rec.ws = t0 + ws;
-                rec.tok_base = 0;
-                rec.out_pos = 0;
-                rec.len = known_end ? nb : -1;
-                rec.wpos = pos;
-                rec.cnt = 0;
-                rec.tile = (uint32_t)tile;
-                W.exc[slot] = rec;
-            } else {
-                raise(A.err, HUTK_E_MEMORY);
+    uint32_t* run_out = W.run + tile * RUN_STRIDE;  // symbols; k_gather turns them into ids
+    {
+        uint32_t pos = run & 0xFFFFu, eidx = run >> 16;
+        uint32_t ev = live16 | exc16;
+        if (PREFIXED && T.has_prefix) ev |= own;  // arena words have no live bit of their own
+        for (; ev; ev &= ev - 1) {
+            const int j = __builtin_ctz(ev);
+            const int ws = 16 * lane + j;
+            if ((exc16 >> j) & 1u) {
+                const uint64_t slot = (uint64_t)exc_first + eidx;
+                if ((int64_t)slot < W.cap_exc) {
+                    const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+                    const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                    const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                    ExcRec rec;
+                    rec.ws = t0 + ws;
+                    rec.tok_base = 0;
+                    rec.out_pos = 0;
+                    rec.len = known_end ? nb : -1;
+                    rec.wpos = pos;
+                    rec.cnt = 0;
+                    rec.tile = (uint32_t)tile;
+                    W.exc[slot] = rec;
+                } else {
+                    raise(A.err, HUTK_E_MEMORY);
+                }
+                eidx++;
+                continue;
             }
-            run += 0x10000u;
-        } else {
-            const uint32_t na = alone_ids(ws);
-            run += (uint32_t)__popc(sv) + na;
-            for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_syms[i];
-            for (; sv; sv &= sv - 1)  // surviving units, left to right (stores only: nothing here waits)
-                run_out[pos++] = Sym<SymT>::widen(base[__builtin_ctz(sv)]);
+            if (PREFIXED && T.has_prefix && ((own >> j) & 1u) && bit_at(docm, ws + LOOKBACK)) {
+                const int a = arena_at(ws);
+                if (a >= 0) {
+                    for (uint32_t sv = arena_live[a]; sv; sv &= sv - 1)
+                        run_out[pos++] = Sym<SymT>::widen(arenaS[a * ARENA_W + __builtin_ctz(sv)]);
+                    continue;
+                }
+                const uint32_t na = alone_ids(ws);
+                for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_syms[i];
+            }
+            if ((live16 >> j) & 1u) run_out[pos++] = Sym<SymT>::widen(S[ws]);  // stores only: nothing here waits
         }
     }
     wave_sync();
@@ -753,15 +795,10 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
         if (o < t0) continue;
         const int r = (int)(o - t0);
         const int lr = r >> 4;
+        const uint32_t below = (1u << (r & 15)) - 1u;
         uint32_t before = lanepref[lr];
-        uint32_t fl = wmask16[lr] & ((1u << (r & 15)) - 1u);
-        for (; fl; fl &= fl - 1) {
-            bool is_exc;
-            const SymT* base;
-            const int wp = 16 * lr + __builtin_ctz(fl);
-            const uint32_t sv = survivors(wp, &is_exc, &base);
-            if (!is_exc) before += (uint32_t)__popc(sv) + alone_ids(wp);
-        }
+        before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(livem)[lr] & below);
+        before += extra_ids(lr, wmask16[lr] & below);
         W.doc_tile_pos[d] = before;
     }
     HUTK_STAMP(8);
