@@ -233,8 +233,7 @@ HUTK_CLS_HD uint32_t classify16(const uint32_t (&d)[8], uint32_t dbits, bool* ex
         uint32_t h = 0;
         uint32_t todo = movemask4(v2[q] & c3c5[q]);
         while (todo) {
-            int j = 0;
-            while (!((todo >> j) & 1u)) j++;
+            const int j = __builtin_ctz(todo);
             todo &= todo - 1;
             // lead at byte j of dword q, follower right after it (possibly byte 0 of dword q + 1); q is a
             // compile-time constant here, so no register array is indexed dynamically (scratch)

@@ -381,10 +381,17 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             flags = classify16_exact_cold(w8, dbits);
         }
     }
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const int64_t p = t0 + 16 * lane + j;
-        if (p < tile_end && win_byte(w, 8 + j) == 0) raise(A.err, HUTK_E_NUL_BYTE);
+    {  // a 0x00 byte inside the data is an error (the reference's strings end there): any zero among my 16 bytes?
+        const int64_t valid = tile_end - (t0 + 16 * lane);  // my positions that are data of this tile
+        const uint64_t lo = w.b, hi = w.c;                  // window bytes 8..15 and 16..23
+        const uint64_t K1 = 0x0101010101010101ull, K8 = 0x8080808080808080ull;
+        uint64_t zlo = (lo - K1) & ~lo & K8, zhi = (hi - K1) & ~hi & K8;  // lowest set flag is exact
+        if (valid < 16) {
+            const int v = valid < 0 ? 0 : (int)valid;
+            zlo &= v >= 8 ? ~0ull : ((1ull << (8 * v)) - 1ull);
+            zhi &= v <= 8 ? 0ull : ((1ull << (8 * (v - 8))) - 1ull);
+        }
+        if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
     }
     wmask16[lane] = (uint16_t)flags;
     HUTK_STAMP(2);
