@@ -243,6 +243,7 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // No workgroup barriers: a long word delays only its own wavefront.
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
+constexpr int TILE_WAVES = 4;  // tiles (= wavefronts) per workgroup of k_tiles
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
 
@@ -268,32 +269,60 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_
     return inc - v;
 }
 
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM>
-__global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
-    static_assert(TILE_THREADS == 64, "k_tiles is one wavefront per workgroup (wave_sync)");
-    __shared__ __attribute__((aligned(16))) uint8_t sb[WINDOW];
-    __shared__ uint32_t docm[WINDOW / 32 + 3];
-    __shared__ __attribute__((aligned(8))) uint16_t wmask16[64 + 8];  // word starts, 16 positions per entry
-    __shared__ __attribute__((aligned(8))) uint32_t mergem[NPOS / 32 + 2];  // positions whose word needs the merge loop
-    __shared__ uint16_t stage[64];  // word starts handed to the lanes, 64 at a time; the epilogue's lane prefix later
-    __shared__ __attribute__((aligned(8))) uint32_t excm[NPOS / 32 + 2];   // starts of exception words
-    __shared__ __attribute__((aligned(8))) uint32_t livem[NPOS / 32 + 2];  // surviving units (see phase 5)
-    __shared__ __attribute__((aligned(16))) SymT S[NPOS];   // symbol of unit i of the word at ws: S[ws + i]
-    constexpr int MARENA = 512;                             // pair results of one round of merge-loop words
-    __shared__ __attribute__((aligned(16))) SymT Mar[MARENA];
-    __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
-    __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
+// Per-tile LDS state.  A workgroup is WAVES wavefronts and owns WAVES consecutive tiles; each wavefront works on
+// its own tile except in the merge phase, where the words of all tiles are pooled (phase 6).
+template <typename SymT, bool BYTE_MODE>
+struct TileLds {
+    static constexpr int ARENA_WORDS = 4, ARENA_W = LANE_MAX_UNITS + 4;
+    __attribute__((aligned(16))) uint8_t sb[WINDOW];
+    uint32_t docm[WINDOW / 32 + 3];
+    __attribute__((aligned(8))) uint16_t wmask16[64 + 8];       // word starts, 16 positions per entry
+    __attribute__((aligned(8))) uint32_t mergem[NPOS / 32 + 2];  // words still waiting for the merge loop
+    __attribute__((aligned(8))) uint32_t excm[NPOS / 32 + 2];    // starts of exception words
+    __attribute__((aligned(8))) uint32_t livem[NPOS / 32 + 2];   // surviving units (see phase 5)
+    uint16_t stage[64];  // word starts handed to the lanes, 64 at a time; the epilogue's lane prefix later
+    __attribute__((aligned(16))) SymT S[NPOS];  // symbol of unit i of the word at ws: S[ws + i]
+    __attribute__((aligned(16))) SymT M[NPOS];  // merge loop: pair result of units (i, next live) at M[ws + i]
     // non-byte mode with a prefix: the first word of a document gets the prefix units in front of its own,
     // which does not fit its byte span; up to ARENA_WORDS such words per tile keep their units in this side
     // arena (more than that: exception path)
-    constexpr int ARENA_WORDS = 4, ARENA_W = LANE_MAX_UNITS + 4;
-    __shared__ SymT arenaS[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
-    __shared__ uint32_t arena_live[ARENA_WORDS];  // their surviving units
-    __shared__ uint16_t arena_ws[ARENA_WORDS], arena_n[ARENA_WORDS];
-    __shared__ uint32_t s_arena_used, s_extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
+    SymT arenaS[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
+    SymT arenaM[BYTE_MODE ? 1 : ARENA_WORDS * ARENA_W];
+    uint32_t arena_live[ARENA_WORDS];  // their surviving units
+    uint16_t arena_ws[ARENA_WORDS], arena_n[ARENA_WORDS];
+    uint32_t arena_used, extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
+};
 
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE_MODE ? 6 : 5))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+    typedef TileLds<SymT, BYTE_MODE> Tile;
+    constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
+    constexpr int POOL_CAP = 128 * WAVES, POOL_LONG_CAP = 48 * WAVES, POOL_LONG = 8;
+    static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
+    __shared__ Tile L[WAVES];
+    __shared__ uint16_t pool[POOL_CAP];
+    __shared__ uint32_t pool_cnt[2];
+    __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
+    __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
+
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
+    const bool tile_ok = tile < A.n_tiles;  // a wavefront without a tile still merges pooled words
+    Tile& me = L[wv];
+    uint8_t* const sb = me.sb;
+    uint32_t* const docm = me.docm;
+    uint16_t* const wmask16 = me.wmask16;
+    uint32_t* const mergem = me.mergem;
+    uint32_t* const excm = me.excm;
+    uint32_t* const livem = me.livem;
+    uint16_t* const stage = me.stage;
+    SymT* const S = me.S;
+    SymT* const arenaS = me.arenaS;
+    uint32_t* const arena_live = me.arena_live;
+    uint16_t* const arena_ws = me.arena_ws;
+    uint16_t* const arena_n = me.arena_n;
+    uint32_t& s_arena_used = me.arena_used;
+    uint32_t& s_extra = me.extra;
     auto RK = [&](uint32_t merged) -> uint32_t {  // rank used in comparisons
         if (RANK_IS_SYM) return merged;
         return (uint32_t)T.sym_id[merged] ^ 0x80000000u;  // signed id order as unsigned
@@ -318,392 +347,434 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tiles(DevTables T, BatchArgs A
             c = c3 & (c3 - 1);
         }
     };
+    // units of the lane-path word that starts at position ws of tile X
+    auto word_units = [&](Tile& X, int ws) -> int {
+        const int nb = 1 + __builtin_ctzll(bits64(reinterpret_cast<const uint32_t*>(X.wmask16), ws + 1));
+        if (BYTE_MODE) return nb;
+        for (int a = 0; a < ARENA_WORDS; a++)
+            if (X.arena_ws[a] == ws) return X.arena_n[a];
+        int n = 0;  // units = characters = lead bytes
+        for (int i = 0; i < nb; i++) n += !is_cont(X.sb[ws + LOOKBACK + i]);
+        return n;
+    };
     const int64_t t0 = tile * TILE_BYTES;
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
     const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
-    HUTK_STAMP(0);
-
-    // ---- 1. stage bytes and tables ------------------------------------------------
-    for (int c = lane; c < WINDOW / 16; c += 64) {
-        const int64_t p = gw + 16 * c;
-        if (p >= 0 && p + 16 <= A.n_bytes) {
-            *reinterpret_cast<uint4*>(sb + 16 * c) = *reinterpret_cast<const uint4*>(A.bytes + p);
-        } else {
-            for (int k = 0; k < 16; k++) {
-                const int64_t q = p + k;
-                sb[16 * c + k] = (q >= 0 && q < A.n_bytes) ? A.bytes[q] : (uint8_t)0;
-            }
-        }
-    }
-    if (!BYTE_MODE)
-        for (int i = lane; i < 256; i += 64) {
+    const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
+    const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
+    uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
+    if (!BYTE_MODE) {
+        for (int i = threadIdx.x; i < 256; i += 64 * WAVES) {
             s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
             s_item_direct[i] = T.item_direct[i];
         }
-    if (lane < WINDOW / 32 + 3) docm[lane] = 0;
-    if (lane < NPOS / 32 + 2) { mergem[lane] = 0; excm[lane] = 0; livem[lane] = 0; }
-    if (lane == 0) { s_arena_used = 0; s_extra = 0; }
-    if (lane < ARENA_WORDS) { arena_ws[lane] = 0xFFFFu; arena_live[lane] = 0; }
-    if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
-    wave_sync();
-
-    // ---- 2. document starts inside the window -------------------------------
-    const int64_t dfirst = W.tile_first_doc[tile];
-    for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
-        const int64_t o = A.offsets[d];
-        if (o >= gw + WINDOW) break;
-        const int li = (int)(o - gw);
-        if (li >= 0) atomicOr(&docm[li >> 5], 1u << (li & 31));
+        __syncthreads();
     }
-    wave_sync();
-    HUTK_STAMP(1);
+    if (tile_ok) {
+        HUTK_STAMP(0);
 
-    // ---- 3. classification in registers: 32-byte window per lane ------------------
-    // window-local index k <-> window index kb - 8 + k; own positions are k = 8..23
-    const int kb = LOOKBACK + 16 * lane;
-    Win w;
-    {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(sb + kb - 8);
-        w.a = src[0]; w.b = src[1]; w.c = src[2]; w.d = src[3];
-    }
-    const uint32_t dbits = (uint32_t)bits64(docm, kb - 8);
-    const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
-    uint32_t flags;
-    {
-        const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
-                                (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
-        bool exotic;
-        flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
-        if (exotic) {  // overlong encodings: per-position decode
-            Win8 w8;
-#pragma unroll
-            for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
-            flags = classify16_exact_cold(w8, dbits);
+        // ---- 1. stage bytes and tables ------------------------------------------------
+        for (int c = lane; c < WINDOW / 16; c += 64) {
+            const int64_t p = gw + 16 * c;
+            if (p >= 0 && p + 16 <= A.n_bytes) {
+                *reinterpret_cast<uint4*>(sb + 16 * c) = *reinterpret_cast<const uint4*>(A.bytes + p);
+            } else {
+                for (int k = 0; k < 16; k++) {
+                    const int64_t q = p + k;
+                    sb[16 * c + k] = (q >= 0 && q < A.n_bytes) ? A.bytes[q] : (uint8_t)0;
+                }
+            }
         }
-    }
-    {  // a 0x00 byte inside the data is an error (the reference's strings end there): any zero among my 16 bytes?
-        const int64_t valid = tile_end - (t0 + 16 * lane);  // my positions that are data of this tile
-        const uint64_t lo = w.b, hi = w.c;                  // window bytes 8..15 and 16..23
-        const uint64_t K1 = 0x0101010101010101ull, K8 = 0x8080808080808080ull;
-        uint64_t zlo = (lo - K1) & ~lo & K8, zhi = (hi - K1) & ~hi & K8;  // lowest set flag is exact
-        if (valid < 16) {
-            const int v = valid < 0 ? 0 : (int)valid;
-            zlo &= v >= 8 ? ~0ull : ((1ull << (8 * v)) - 1ull);
-            zhi &= v <= 8 ? 0ull : ((1ull << (8 * (v - 8))) - 1ull);
+        if (lane < WINDOW / 32 + 3) docm[lane] = 0;
+        if (lane < NPOS / 32 + 2) { mergem[lane] = 0; excm[lane] = 0; livem[lane] = 0; }
+        if (lane == 0) { s_arena_used = 0; s_extra = 0; }
+        if (lane < ARENA_WORDS) { arena_ws[lane] = 0xFFFFu; arena_live[lane] = 0; }
+        if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
+        wave_sync();
+
+        // ---- 2. document starts inside the window -------------------------------
+        for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
+            const int64_t o = A.offsets[d];
+            if (o >= gw + WINDOW) break;
+            const int li = (int)(o - gw);
+            if (li >= 0) atomicOr(&docm[li >> 5], 1u << (li & 31));
         }
-        if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
-    }
-    wmask16[lane] = (uint16_t)flags;
-    HUTK_STAMP(2);
+        wave_sync();
+        HUTK_STAMP(1);
 
-    wave_sync();
-    HUTK_STAMP(3);
-
-    // ---- 5. words, spread evenly over the lanes: whole-word table; mark what needs merging ----
-    // Word j of the tile goes to lane j % 64: every round the owning lanes put the starts of words
-    // [r0, r0 + 64) into a 64-entry staging buffer (no per-tile word list is kept in LDS: its
-    // footprint would cost resident wavefronts, and residency is what hides the gather latency).
-    //
-    // State handed to the epilogue, all of it bitmaps over tile positions:
-    //   livem  units that survive: starts as "every word start" (the first unit of a word always
-    //          survives); the merge loop adds the other survivors of its words (unit i of the word at ws
-    //          is bit ws + i, and S[ws + i] its symbol); exception and arena words are taken out
-    //   excm   starts of exception words
-    const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
-    uint32_t own = flags;                    // starts that are words of this tile
-    {
-        const int lo = 16 * lane;
-        if (lo >= limit) own = 0;
-        else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
-    }
-    reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
-    uint32_t nW;
-    const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
-    for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
+        // ---- 3. classification in registers: 32-byte window per lane ------------------
+        // window-local index k <-> window index kb - 8 + k; own positions are k = 8..23
+        const int kb = LOOKBACK + 16 * lane;
+        Win w;
         {
-            uint32_t wi = wbase - r0;
-            for (uint32_t m = own; m; m &= m - 1, wi++)
-                if (wi < 64u) stage[wi] = (uint16_t)(16 * lane + __builtin_ctz(m));
+            const uint64_t* src = reinterpret_cast<const uint64_t*>(sb + kb - 8);
+            w.a = src[0]; w.b = src[1]; w.c = src[2]; w.d = src[3];
         }
-        wave_sync();
-        if (r0 + lane < nW) {
-            const int ws = stage[lane];
-            // end of the word: the next start bit within 63 positions (bits beyond the
-            // window are ones, which is only true when the data ends there)
-            const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-            const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-            const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
-            const bool docfirst = bit_at(docm, ws + LOOKBACK);
-            const uint32_t b0 = sb[ws + LOOKBACK];
-            // first word of a document with a prefix configured (core.c:364-366, 421-451): a leading space
-            // means "prefix ids as a word of their own, then the word as it is" (handled in the epilogue);
-            // otherwise the prefix units go in front of the word's own units (arena)
-            const bool pfx = T.has_prefix && docfirst && b0 != ' ';
-            bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
-            if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
-                exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
-            // Every global load of this round is issued here, unconditionally and together, so that the round
-            // costs one memory round trip whatever mix of words the lanes hold:
-            //   byte mode: symbol of the first byte (all a one-byte word needs)
-            //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
-            //   encodes to; two-choice cuckoo table, entries verified by this pipeline at context creation
-            const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
-            uint32_t k0, k1, k2, k3;
-            {
-                const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
-                const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
-                const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
-                k0 = q0; k1 = q1; k2 = q2; k3 = q3;
-                if (o8) {
-                    k0 = funnel_r(q1, q0, o8);
-                    k1 = funnel_r(q2, q1, o8);
-                    k2 = funnel_r(q3, q2, o8);
-                    k3 = funnel_r(q4, q3, o8);
-                }
-                // zero the bytes at and beyond nb
-                const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
-                const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
-                if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
-                else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
-                else if (full == 2) { k2 &= keep; k3 = 0; }
-                else if (full == 3) { k3 &= keep; }
+        const uint32_t dbits = (uint32_t)bits64(docm, kb - 8);
+        uint32_t flags;
+        {
+            const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
+                                    (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
+            bool exotic;
+            flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
+            if (exotic) {  // overlong encodings: per-position decode
+                Win8 w8;
+    #pragma unroll
+                for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
+                flags = classify16_exact_cold(w8, dbits);
             }
-            const uint32_t h1 = probe ? word_hash(k0, k1, k2, k3) & T.word_mask : 0u;
-            const uint32_t h2 = probe ? word_hash2(k0, k1, k2, k3) & T.word_mask : 0u;
-            uint4 key1 = make_uint4(0, 0, 0, 0), key2 = key1;
-            uint32_t sym1 = 0, sym2 = 0, isym = 0;
-            if (T.word_mask) {  // uniform
-                key1 = T.word_keys[h1];
-                key2 = T.word_keys[h2];
-                sym1 = T.word_syms[h1];
-                sym2 = T.word_syms[h2];
-            }
-            if (BYTE_MODE) isym = T.item_sym[b0];
-            bool done = false;
-            if (probe) {
-                // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
-                const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
-                const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
-                done = hit1 || hit2;
-                if (done) S[ws] = Sym<SymT>::narrow(hit1 ? sym1 : sym2);
-            }
-            int n = 0;
-            SymT* Sdst = S + ws;
-            int slot = -1;
-            if (!BYTE_MODE && !exc && pfx) {
-                slot = (int)atomicAdd(&s_arena_used, 1u);
-                if (slot >= ARENA_WORDS ||
-                    atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
-                else {
-                    Sdst = arenaS + slot * ARENA_W;
-                    for (int i = 0; i < T.n_prefix && i < ARENA_W; i++) Sdst[i] = Sym<SymT>::narrow(T.prefix_syms[i]);
-                    n = T.n_prefix;
-                }
-            }
-            const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
-            if (!exc && !done) {
-                if (BYTE_MODE) {
-                    n = nb;
-                } else {
-                    const int lw = ws + LOOKBACK;
-                    int i = 0;
-                    while (i < nb) {
-                        const uint32_t b = sb[lw + i];
-                        int L = 1;
-                        if (b >= 0x80u) {
-                            L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
-                            if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
-                        }
-                        uint32_t sym;
-                        if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
-                        else if (L == 1) sym = SYM_UNK;
-                        else {
-                            uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
-                            if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
-                            if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
-                            sym = char_lookup(T, packed);
-                        }
-                        if (n < n_cap) Sdst[n] = Sym<SymT>::narrow(sym);
-                        n++;
-                        i += L;
-                    }
-                }
-                if (n > LANE_MAX_UNITS) exc = true;
-            }
-            if (done) {
-            } else if (!BYTE_MODE && !exc && pfx) {  // arena word: at least two units, always through the merge loop
-                arena_ws[slot] = (uint16_t)ws;
-                arena_n[slot] = (uint16_t)n;
-                atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));  // its ids are counted from arena_live[]
-            } else if (exc) {
-                atomicOr(&excm[ws >> 5], 1u << (ws & 31));
-                atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));
-                done = true;
-            } else if (n == 1) {  // a single unit: nothing to merge
-                if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(isym);
-                done = true;
-            }
-            if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
         }
-        wave_sync();
-    }
-    HUTK_STAMP(4);
+        {  // a 0x00 byte inside the data is an error (the reference's strings end there): any zero among my 16 bytes?
+            const int64_t valid = tile_end - (t0 + 16 * lane);  // my positions that are data of this tile
+            const uint64_t lo = w.b, hi = w.c;                  // window bytes 8..15 and 16..23
+            const uint64_t K1 = 0x0101010101010101ull, K8 = 0x8080808080808080ull;
+            uint64_t zlo = (lo - K1) & ~lo & K8, zhi = (hi - K1) & ~hi & K8;  // lowest set flag is exact
+            if (valid < 16) {
+                const int v = valid < 0 ? 0 : (int)valid;
+                zlo &= v >= 8 ? ~0ull : ((1ull << (8 * v)) - 1ull);
+                zhi &= v <= 8 ? 0ull : ((1ull << (8 * (v - 8))) - 1ull);
+            }
+            if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
+        }
+        wmask16[lane] = (uint16_t)flags;
+        HUTK_STAMP(2);
 
-    // ---- 6. merge: ONE LANE PER WORD, one merge step per trip ------------------------
-    // Each lane keeps (br, bp, bm) = rank, position and merged symbol of its word's best pair.
-    // A step applies that merge, ISSUES the pair-table loads for the two new neighbour pairs,
-    // rescans the untouched candidates in LDS while those loads are in flight, and then
-    // picks the next best among {rescan, new left pair, new right pair}.
-    // Pair results live in a small arena (Mar) handed out per round: only about one word in ten gets here,
-    // and a position-indexed array for them would cost a quarter of the resident wavefronts.
-    {
-        const uint32_t mown = reinterpret_cast<const uint16_t*>(mergem)[lane];
-        uint32_t nM;
-        const uint32_t mbase = wave_excl_scan(__popc(mown), lane, &nM);
-        for (uint32_t r0 = 0; r0 < nM;) {
+        wave_sync();
+        HUTK_STAMP(3);
+
+        // ---- 5. words, spread evenly over the lanes: whole-word table; mark what needs merging ----
+        // Word j of the tile goes to lane j % 64: every round the owning lanes put the starts of words
+        // [r0, r0 + 64) into a 64-entry staging buffer (no per-tile word list is kept in LDS: its
+        // footprint would cost resident wavefronts, and residency is what hides the gather latency).
+        //
+        // State handed to the epilogue, all of it bitmaps over tile positions:
+        //   livem  units that survive: starts as "every word start" (the first unit of a word always
+        //          survives); the merge loop adds the other survivors of its words (unit i of the word at ws
+        //          is bit ws + i, and S[ws + i] its symbol); exception and arena words are taken out
+        //   excm   starts of exception words
+        const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
+        own = flags;                             // starts that are words of this tile
+        {
+            const int lo = 16 * lane;
+            if (lo >= limit) own = 0;
+            else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
+        }
+        reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
+        uint32_t nW;
+        const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
+        for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
             {
-                uint32_t mi = mbase - r0;
-                for (uint32_t m = mown; m; m &= m - 1, mi++)
-                    if (mi < 64u) stage[mi] = (uint16_t)(16 * lane + __builtin_ctz(m));
+                uint32_t wi = wbase - r0;
+                for (uint32_t m = own; m; m &= m - 1, wi++)
+                    if (wi < 64u) stage[wi] = (uint16_t)(16 * lane + __builtin_ctz(m));
             }
             wave_sync();
-            bool have = r0 + lane < nM;
-            const int ws = have ? stage[lane] : 0;
-            SymT* Sw = S + ws;
+            if (r0 + lane < nW) {
+                const int ws = stage[lane];
+                // end of the word: the next start bit within 63 positions (bits beyond the
+                // window are ones, which is only true when the data ends there)
+                const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
+                const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                const bool docfirst = bit_at(docm, ws + LOOKBACK);
+                const uint32_t b0 = sb[ws + LOOKBACK];
+                // first word of a document with a prefix configured (core.c:364-366, 421-451): a leading space
+                // means "prefix ids as a word of their own, then the word as it is" (handled in the epilogue);
+                // otherwise the prefix units go in front of the word's own units (arena)
+                const bool pfx = T.has_prefix && docfirst && b0 != ' ';
+                bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
+                if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
+                    exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
+                // Every global load of this round is issued here, unconditionally and together, so that the round
+                // costs one memory round trip whatever mix of words the lanes hold:
+                //   byte mode: symbol of the first byte (all a one-byte word needs)
+                //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
+                //   encodes to; two-choice cuckoo table, entries verified by this pipeline at context creation
+                const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
+                uint32_t k0, k1, k2, k3;
+                {
+                    const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
+                    const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
+                    const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
+                    k0 = q0; k1 = q1; k2 = q2; k3 = q3;
+                    if (o8) {
+                        k0 = funnel_r(q1, q0, o8);
+                        k1 = funnel_r(q2, q1, o8);
+                        k2 = funnel_r(q3, q2, o8);
+                        k3 = funnel_r(q4, q3, o8);
+                    }
+                    // zero the bytes at and beyond nb
+                    const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
+                    const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
+                    if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
+                    else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
+                    else if (full == 2) { k2 &= keep; k3 = 0; }
+                    else if (full == 3) { k3 &= keep; }
+                }
+                const uint32_t h1 = probe ? word_hash(k0, k1, k2, k3) & T.word_mask : 0u;
+                const uint32_t h2 = probe ? word_hash2(k0, k1, k2, k3) & T.word_mask : 0u;
+                uint4 key1 = make_uint4(0, 0, 0, 0), key2 = key1;
+                uint32_t sym1 = 0, sym2 = 0, isym = 0;
+                if (T.word_mask) {  // uniform
+                    key1 = T.word_keys[h1];
+                    key2 = T.word_keys[h2];
+                    sym1 = T.word_syms[h1];
+                    sym2 = T.word_syms[h2];
+                }
+                if (BYTE_MODE) isym = T.item_sym[b0];
+                bool done = false;
+                if (probe) {
+                    // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
+                    const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
+                    const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
+                    done = hit1 || hit2;
+                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? sym1 : sym2);
+                }
+                int n = 0;
+                SymT* Sdst = S + ws;
+                int slot = -1;
+                if (!BYTE_MODE && !exc && pfx) {
+                    slot = (int)atomicAdd(&s_arena_used, 1u);
+                    if (slot >= ARENA_WORDS ||
+                        atomicAdd(&s_extra, (uint32_t)T.n_prefix) + T.n_prefix > (uint32_t)RUN_EXTRA) exc = true;
+                    else {
+                        Sdst = arenaS + slot * ARENA_W;
+                        for (int i = 0; i < T.n_prefix && i < ARENA_W; i++) Sdst[i] = Sym<SymT>::narrow(T.prefix_syms[i]);
+                        n = T.n_prefix;
+                    }
+                }
+                const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
+                if (!exc && !done) {
+                    if (BYTE_MODE) {
+                        n = nb;
+                    } else {
+                        const int lw = ws + LOOKBACK;
+                        int i = 0;
+                        while (i < nb) {
+                            const uint32_t b = sb[lw + i];
+                            int L = 1;
+                            if (b >= 0x80u) {
+                                L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                                if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
+                            }
+                            uint32_t sym;
+                            if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
+                            else if (L == 1) sym = SYM_UNK;
+                            else {
+                                uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
+                                if (L > 2) packed |= (uint32_t)sb[lw + i + 2] << 16;
+                                if (L > 3) packed |= (uint32_t)sb[lw + i + 3] << 24;
+                                sym = char_lookup(T, packed);
+                            }
+                            if (n < n_cap) Sdst[n] = Sym<SymT>::narrow(sym);
+                            n++;
+                            i += L;
+                        }
+                    }
+                    if (n > LANE_MAX_UNITS) exc = true;
+                }
+                if (done) {
+                } else if (!BYTE_MODE && !exc && pfx) {  // arena word: at least two units, always through the merge loop
+                    arena_ws[slot] = (uint16_t)ws;
+                    arena_n[slot] = (uint16_t)n;
+                    atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));  // its ids are counted from arena_live[]
+                } else if (exc) {
+                    atomicOr(&excm[ws >> 5], 1u << (ws & 31));
+                    atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));
+                    done = true;
+                } else if (n == 1) {  // a single unit: nothing to merge
+                    if (BYTE_MODE) S[ws] = Sym<SymT>::narrow(isym);
+                    done = true;
+                }
+                if (!done) atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
+            }
+            wave_sync();
+        }
+        HUTK_STAMP(4);
+
+    }
+
+    // ---- 6. merge: the workgroup POOLS the merge-loop words of its WAVES tiles ------------------------
+    // One lane per word, one merge step per trip, and a wavefront runs as many trips as its longest word
+    // needs.  A tile has ~20 such words, a few of them long: merged by its own wavefront, 2/3 of the lanes
+    // would idle and every tile would pay the long trip count.  Pooled, the words fill whole wavefronts, long
+    // ones first, and the short rest finishes in a few trips.  The instruction stream is what bounds this
+    // kernel, so that is worth three workgroup barriers.
+    //   pool[0 .. n_long)              words with more than POOL_LONG units
+    //   pool[POOL_CAP-1 downto ...]    the others; an entry is (tile-in-workgroup << 10) | word start
+    // Words that do not fit stay in their tile's mergem and go into the next epoch (rare).
+    for (;;) {
+        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; }
+        __syncthreads();
+        uint32_t pending = 0;
+        if (tile_ok) {
+            pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
+            for (uint32_t m = pending; m; m &= m - 1) {
+                const int j = __builtin_ctz(m);
+                const int ws = 16 * lane + j;
+                const int n = word_units(me, ws);
+                const bool is_long = n > POOL_LONG;
+                const uint32_t idx = atomicAdd(&pool_cnt[is_long ? 0 : 1], 1u);
+                if (idx < (uint32_t)(is_long ? POOL_LONG_CAP : POOL_CAP - POOL_LONG_CAP)) {
+                    pool[is_long ? idx : POOL_CAP - 1 - idx] = (uint16_t)((wv << 10) | ws);
+                    pending &= ~(1u << j);
+                }
+            }
+            reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)pending;
+        }
+        __syncthreads();
+        const uint32_t n_long = min(pool_cnt[0], (uint32_t)POOL_LONG_CAP);
+        const uint32_t n_pool = n_long + min(pool_cnt[1], (uint32_t)(POOL_CAP - POOL_LONG_CAP));
+        for (uint32_t base = 64u * wv; base < n_pool; base += 64u * WAVES) {
+            const uint32_t wi = base + lane;
+            bool have = wi < n_pool;
+            const uint32_t entry = have ? (wi < n_long ? pool[wi] : pool[POOL_CAP - 1 - (wi - n_long)]) : 0u;
+            Tile& X = L[entry >> 10];  // the word's tile
+            const int ws = entry & 1023;
+            SymT* Sw = X.S + ws;
+            SymT* Mw = X.M + ws;
             int arena_slot = -1;
-            int n = 0, nb = 0;
+            int n = 0;
             if (have) {
-                nb = 1 + __builtin_ctzll(bits64(wmask32, ws + 1));  // a lane word's end is in sight
-                n = nb;
-                if (!BYTE_MODE) {  // units = characters = lead bytes (+ the prefix units of an arena word)
-                    n = 0;
-                    for (int i = 0; i < nb; i++) n += !is_cont(sb[ws + LOOKBACK + i]);
+                n = word_units(X, ws);
+                if (!BYTE_MODE)
                     for (int a = 0; a < ARENA_WORDS; a++)
-                        if (arena_ws[a] == ws) {
-                            Sw = arenaS + a * ARENA_W;
-                            n = arena_n[a];
+                        if (X.arena_ws[a] == ws) {
+                            Sw = X.arenaS + a * ARENA_W;
+                            Mw = X.arenaM + a * ARENA_W;
                             arena_slot = a;
                         }
-                }
             }
-            // arena space for this round: the first k words whose pair results fit (n <= 32, so k >= 16)
-            const uint32_t need = have ? (uint32_t)((n + 7) & ~7) : 0u;
-            uint32_t need_total;
-            const uint32_t moff = wave_excl_scan(need, lane, &need_total);
-            have = have && moff + need <= (uint32_t)MARENA;
-            const uint32_t k_round = (uint32_t)__popcll(__ballot(have));
-            SymT* Mw = Mar + (have ? moff : 0u);
-            uint32_t live = 0, cand = 0;  // lane words have at most 32 units
-            uint32_t br = 0xFFFFFFFFu;
-            int bp = 0;
-            SymT bm = 0;
-            if (have) {
-                live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-                if (BYTE_MODE) {
-                    // symbols and initial pair results of THIS word only, one load per unit from the
-                    // 65536-entry (byte, next byte) table: ~11 % of the words get here
-                    const uint8_t* wb = sb + ws + LOOKBACK;
-                    for (int i0 = 0; i0 < n; i0 += 16) {
-                        typename Sym<SymT>::Pair e[16];
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
-                            const int i = i0 + j;
-                            const uint32_t b = (i < n) ? wb[i] : 0u, b2 = (i + 1 < n) ? wb[i + 1] : 0u;
-                            e[j] = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair)[(b << 8) | b2];
-                        }
-#pragma unroll
-                        for (int j = 0; j < 16; j++) {
-                            const int i = i0 + j;
-                            if (i < n) {
-                                const SymT mv = Sym<SymT>::pair_merged(e[j]);
-                                Sw[i] = Sym<SymT>::pair_sym(e[j]);
-                                Mw[i] = mv;
-                                if (i + 1 < n && mv != Sym<SymT>::NONE) cand |= 1u << i;
-                            }
-                        }
-                    }
-                } else {
-                    for (int i = 0; i + 1 < n; i++) {
-                        const uint32_t m = pair_lookup(T, Sym<SymT>::widen(Sw[i]), Sym<SymT>::widen(Sw[i + 1]));
-                        Mw[i] = Sym<SymT>::narrow(m);
-                        if (m != SYM_NONE) cand |= 1u << i;
-                    }
-                }
-                scan_best(cand, Mw, br, bp, bm);
-            }
-            for (;;) {
-                if (have && cand == 0) {
-                    // done: publish the surviving units (unit 0 always survives and is already in livem)
-                    if (!BYTE_MODE && arena_slot >= 0) {
-                        arena_live[arena_slot] = live;
-                    } else {
-                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
-                        if ((uint32_t)lm) atomicOr(&livem[ws >> 5], (uint32_t)lm);
-                        if ((uint32_t)(lm >> 32)) atomicOr(&livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
-                    }
-                    have = false;
-                }
-                if (!__any(have)) break;
+            {
+                uint32_t live = 0, cand = 0;  // lane words have at most 32 units
+                uint32_t br = 0xFFFFFFFFu;
+                int bp = 0;
+                SymT bm = 0;
                 if (have) {
-                    const int p = bp;
-                    const uint32_t merged = Sym<SymT>::widen(bm);
-                    // q: next live unit after p (exists: bit p of cand was set)
-                    const uint32_t above = live & ~((2u << p) - 1u);
-                    const int q = __builtin_ctz(above);
-                    Sw[p] = bm;
-                    live &= ~(1u << q);
-                    cand &= ~((1u << q) | (1u << p));
-                    const uint32_t right = above & (above - 1u);    // live units after q
-                    const uint32_t left = live & ((1u << p) - 1u);  // live units before p
-                    const int q2 = right ? __builtin_ctz(right) : 0;
-                    const int p0 = left ? 31 - __builtin_clz(left) : 0;
-                    const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
-                    const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
-                    // issue the lookups of both new pairs: four independent loads (unconditional: a
-                    // missing neighbour reads as symbol 0, and the result is discarded)
-                    const PairProbe s1 = pair_issue(T, merged, sr);
-                    const PairProbe s2 = pair_issue(T, sl, merged);
-                    // rescan what the merge did not touch
-                    if (left) cand &= ~(1u << p0);
-                    br = 0xFFFFFFFFu;
-                    scan_best(cand, Mw, br, bp, bm);
-                    // the two new pairs
-                    const uint32_t mr = right ? pair_resolve(s1, merged, sr) : SYM_NONE;
-                    const uint32_t ml = left ? pair_resolve(s2, sl, merged) : SYM_NONE;
-                    if (right) {
-                        const SymT mn = Sym<SymT>::narrow(mr);
-                        Mw[p] = mn;
-                        if (mr != SYM_NONE) {
-                            cand |= 1u << p;
-                            const uint32_t r = RK(mr);
-                            if (r < br || (r == br && p < bp)) {
-                                br = r;
-                                bp = p;
-                                bm = mn;
+                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                    if (BYTE_MODE) {
+                        // symbols and initial pair results, one load per unit from the 65536-entry
+                        // (byte, next byte) table
+                        const uint8_t* wb = X.sb + ws + LOOKBACK;
+                        for (int i0 = 0; i0 < n; i0 += 16) {
+                            typename Sym<SymT>::Pair e[16];
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
+                                const int i = i0 + j;
+                                const uint32_t b = (i < n) ? wb[i] : 0u, b2 = (i + 1 < n) ? wb[i + 1] : 0u;
+                                e[j] = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair)[(b << 8) | b2];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 16; j++) {
+                                const int i = i0 + j;
+                                if (i < n) {
+                                    const SymT mv = Sym<SymT>::pair_merged(e[j]);
+                                    Sw[i] = Sym<SymT>::pair_sym(e[j]);
+                                    Mw[i] = mv;
+                                    if (i + 1 < n && mv != Sym<SymT>::NONE) cand |= 1u << i;
+                                }
+                            }
+                        }
+                    } else {
+                        for (int i0 = 0; i0 + 1 < n; i0 += 4) {  // four lookups (eight loads) in flight
+                            PairProbe pr[4];
+                            uint32_t sl[5];
+#pragma unroll
+                            for (int j = 0; j < 5; j++) sl[j] = (i0 + j < n) ? Sym<SymT>::widen(Sw[i0 + j]) : 0u;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sl[j], sl[j + 1]);
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int i = i0 + j;
+                                if (i + 1 < n) {
+                                    const uint32_t m = pair_resolve(pr[j], sl[j], sl[j + 1]);
+                                    Mw[i] = Sym<SymT>::narrow(m);
+                                    if (m != SYM_NONE) cand |= 1u << i;
+                                }
                             }
                         }
                     }
-                    if (left) {
-                        const SymT mn = Sym<SymT>::narrow(ml);
-                        Mw[p0] = mn;
-                        if (ml != SYM_NONE) {
-                            cand |= 1u << p0;
-                            const uint32_t r = RK(ml);
-                            if (r < br || (r == br && p0 < bp)) {
-                                br = r;
-                                bp = p0;
-                                bm = mn;
+                    scan_best(cand, Mw, br, bp, bm);
+                }
+                // Each lane keeps (br, bp, bm) = rank, position and merged symbol of its word's best pair.
+                // A trip applies that merge, ISSUES the pair-table loads for the two new neighbour pairs,
+                // rescans the untouched candidates in LDS while those loads are in flight, and then picks
+                // the next best among {rescan, new left pair, new right pair}.
+                for (;;) {
+                    if (have && cand == 0) {
+                        // done: publish the surviving units (unit 0 always survives and is already in livem)
+                        if (!BYTE_MODE && arena_slot >= 0) {
+                            X.arena_live[arena_slot] = live;
+                        } else {
+                            const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                            if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
+                            if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                        }
+                        have = false;
+                    }
+                    if (!__any(have)) break;
+                    if (have) {
+                        const int p = bp;
+                        const uint32_t merged = Sym<SymT>::widen(bm);
+                        // q: next live unit after p (exists: bit p of cand was set)
+                        const uint32_t above = live & ~((2u << p) - 1u);
+                        const int q = __builtin_ctz(above);
+                        Sw[p] = bm;
+                        live &= ~(1u << q);
+                        cand &= ~((1u << q) | (1u << p));
+                        const uint32_t right = above & (above - 1u);    // live units after q
+                        const uint32_t left = live & ((1u << p) - 1u);  // live units before p
+                        const int q2 = right ? __builtin_ctz(right) : 0;
+                        const int p0 = left ? 31 - __builtin_clz(left) : 0;
+                        const uint32_t sr = right ? Sym<SymT>::widen(Sw[q2]) : 0u;
+                        const uint32_t sl = left ? Sym<SymT>::widen(Sw[p0]) : 0u;
+                        // issue the lookups of both new pairs: four independent loads (unconditional: a
+                        // missing neighbour reads as symbol 0, and the result is discarded)
+                        const PairProbe s1 = pair_issue(T, merged, sr);
+                        const PairProbe s2 = pair_issue(T, sl, merged);
+                        // rescan what the merge did not touch
+                        if (left) cand &= ~(1u << p0);
+                        br = 0xFFFFFFFFu;
+                        scan_best(cand, Mw, br, bp, bm);
+                        // the two new pairs
+                        const uint32_t mr = right ? pair_resolve(s1, merged, sr) : SYM_NONE;
+                        const uint32_t ml = left ? pair_resolve(s2, sl, merged) : SYM_NONE;
+                        if (right) {
+                            const SymT mn = Sym<SymT>::narrow(mr);
+                            Mw[p] = mn;
+                            if (mr != SYM_NONE) {
+                                cand |= 1u << p;
+                                const uint32_t r = RK(mr);
+                                if (r < br || (r == br && p < bp)) {
+                                    br = r;
+                                    bp = p;
+                                    bm = mn;
+                                }
+                            }
+                        }
+                        if (left) {
+                            const SymT mn = Sym<SymT>::narrow(ml);
+                            Mw[p0] = mn;
+                            if (ml != SYM_NONE) {
+                                cand |= 1u << p0;
+                                const uint32_t r = RK(ml);
+                                if (r < br || (r == br && p0 < bp)) {
+                                    br = r;
+                                    bp = p0;
+                                    bm = mn;
+                                }
                             }
                         }
                     }
                 }
+                wave_sync();
             }
-            wave_sync();
-            r0 += k_round;
         }
+        if (!__syncthreads_or(pending != 0)) break;
     }
-    HUTK_STAMP(5);
+    if (tile_ok) HUTK_STAMP(5);
 
+    if (!tile_ok) return;
     // ---- 7. per-position epilogue: counts -> scan -> symbols out, exception records ----
     // A lane's ids are the surviving units at ITS 16 positions (whichever word they belong to: units sit
     // inside their word's byte span, so position order is id order), plus -- non-byte mode with a prefix
@@ -1219,18 +1290,21 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_pre, dim3(g), dim3(256), 0, s, a, w);
 }
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    const dim3 g((unsigned)a.n_tiles), b(TILE_THREADS);
-#define HUTK_LAUNCH(ST, BM, RS) hipLaunchKernelGGL((k_tiles<ST, BM, RS>), g, b, 0, s, t, a, w)
+    // byte-encoder mode pools the merge-loop words of TILE_WAVES tiles; the character mode has few words in
+    // the merge loop (its whole-word table covers most of them) and keeps one tile per workgroup
+#define HUTK_LAUNCH(ST, BM, RS, WV)                                                                     \
+    hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)((a.n_tiles + WV - 1) / WV)), dim3(64 * WV), 0, s, \
+                       t, a, w)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
     switch (variant) {
-        case 7: HUTK_LAUNCH(uint16_t, true, true); break;
-        case 6: HUTK_LAUNCH(uint16_t, true, false); break;
-        case 5: HUTK_LAUNCH(uint16_t, false, true); break;
-        case 4: HUTK_LAUNCH(uint16_t, false, false); break;
-        case 3: HUTK_LAUNCH(uint32_t, true, true); break;
-        case 2: HUTK_LAUNCH(uint32_t, true, false); break;
-        case 1: HUTK_LAUNCH(uint32_t, false, true); break;
-        default: HUTK_LAUNCH(uint32_t, false, false); break;
+        case 7: HUTK_LAUNCH(uint16_t, true, true, TILE_WAVES); break;
+        case 6: HUTK_LAUNCH(uint16_t, true, false, TILE_WAVES); break;
+        case 5: HUTK_LAUNCH(uint16_t, false, true, 1); break;
+        case 4: HUTK_LAUNCH(uint16_t, false, false, 1); break;
+        case 3: HUTK_LAUNCH(uint32_t, true, true, TILE_WAVES); break;
+        case 2: HUTK_LAUNCH(uint32_t, true, false, TILE_WAVES); break;
+        case 1: HUTK_LAUNCH(uint32_t, false, true, 1); break;
+        default: HUTK_LAUNCH(uint32_t, false, false, 1); break;
     }
 #undef HUTK_LAUNCH
 }
