@@ -821,7 +821,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    uint32_t* run_out = W.run + tile * RUN_STRIDE;  // symbols; k_gather turns them into ids
+    // symbols in the width the LDS arrays use (k_gather widens them and turns them into ids)
+    SymT* run_out = reinterpret_cast<SymT*>(W.run) + tile * RUN_STRIDE;
     {
         uint32_t pos = run & 0xFFFFu, eidx = run >> 16;
         uint32_t ev = live16 | exc16;
@@ -854,13 +855,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE
                 const int a = arena_at(ws);
                 if (a >= 0) {
                     for (uint32_t sv = arena_live[a]; sv; sv &= sv - 1)
-                        run_out[pos++] = Sym<SymT>::widen(arenaS[a * ARENA_W + __builtin_ctz(sv)]);
+                        run_out[pos++] = arenaS[a * ARENA_W + __builtin_ctz(sv)];
                     continue;
                 }
                 const uint32_t na = alone_ids(ws);
-                for (uint32_t i = 0; i < na; i++) run_out[pos++] = T.prefix_alone_syms[i];
+                for (uint32_t i = 0; i < na; i++) run_out[pos++] = Sym<SymT>::narrow(T.prefix_alone_syms[i]);
             }
-            if ((live16 >> j) & 1u) run_out[pos++] = Sym<SymT>::widen(S[ws]);  // stores only: nothing here waits
+            if ((live16 >> j) & 1u) run_out[pos++] = S[ws];  // stores only: nothing here waits
         }
     }
     wave_sync();
@@ -1220,13 +1221,16 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArg
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
     const uint32_t nexc = W.tile_nexc[tile];
-    const uint32_t* run = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
+    // the run holds 16-bit symbols when the LDS arrays do (T.sym16), else 32-bit ones
+    const uint16_t* run16 = reinterpret_cast<const uint16_t*>(W.run) + tile * RUN_STRIDE + W.tile_run_start[tile];
+    const uint32_t* run32 = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
+    auto run_sym = [&](uint32_t k) -> uint32_t { return T.sym16 ? (uint32_t)run16[k] : run32[k]; };
     if (base + (int64_t)W.tile_count[tile] > A.ids_cap) {
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
         return;
     }
     if (nexc == 0) {
-        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = sym_to_id(T, run[k]);
+        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = sym_to_id(T, run_sym(k));
         return;
     }
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
@@ -1248,7 +1252,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArg
             const uint32_t mid = (lo + hi) >> 1;
             if (e_pos[mid] <= k) lo = mid + 1; else hi = mid;
         }
-        A.ids_out[base + k + e_cum[lo]] = sym_to_id(T, run[k]);
+        A.ids_out[base + k + e_cum[lo]] = sym_to_id(T, run_sym(k));
     }
     for (uint32_t e = 0; e < nexc; e++) {
         const ExcRec r = recs[e];
