@@ -71,6 +71,23 @@ def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores):
     return out
 
 
+def committed_traffic(n_bytes):
+    """HBM-side bytes of one k_tiles launch from the PMC passes of the last committed profile of THIS workload
+    (profiles/<tag>_traffic.json, written by tools/summarize_rocprof.py from separate `rocprofv3 --pmc` runs of
+    the same bench command: counters cannot be collected inside a timed run).  None when there is no profile
+    of a batch of this size."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload_bytes") == n_bytes:
+            best = (float(t["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
+    return best if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +194,7 @@ def main():
         t_tile = sum(tile_ms) / len(tile_ms) / 1e3
         b_alg = n_bytes + 8 * (n_docs + 1) + 4 * n_ids + 4 * n_docs
         achieved = b_alg / t_tile / 1e9
+        traffic, traffic_src = committed_traffic(n_bytes)
         line = {
             "metric": "GB/s input text encoded (GPT-2 vocab) at 1/2/4/8 GPUs; bit-exact ids",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
@@ -190,7 +208,7 @@ def main():
                        "parallelism": f"documents sharded over {world} GPU(s), all-gather of id totals"},
             "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "kernel_ms": round(t_tile * 1e3, 4),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(t_tile * 1e3, 4),
                          "algorithmic_bytes": b_alg},
             "verified_vs_oracle": verified,
             "gen_s": round(t_gen, 2),

@@ -67,7 +67,7 @@ struct hutk_ctx {
     DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
     DevBuf<uint8_t> d_item_direct;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
-    DevBuf<uint4> d_word_keys;
+    DevBuf<uint4> d_word_keys, d_word_short;
     DevBuf<uint32_t> d_word_syms;
     int64_t n_word_entries = 0;
     DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
@@ -158,6 +158,8 @@ int upload_tables(hutk_ctx* c) {
     D.word_keys = nullptr;
     D.word_syms = nullptr;
     D.word_mask = 0;
+    D.word_short = nullptr;
+    D.wordl_mask = 0;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
@@ -235,7 +237,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_keys.release(); c->d_word_syms.release();
+        c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_err.release();
@@ -271,37 +273,63 @@ int build_word_table(hutk_ctx* c) {
         if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
             keep.push_back(i);
     if (keep.empty()) return HUTK_OK;
-    // two-choice cuckoo table (hutk_internal.h); a word that cannot be placed is simply left out
-    uint32_t cap = 1024;
-    while (cap < keep.size() * 5 / 2 + 16) cap <<= 1;
+    // two-choice cuckoo tables (hutk_internal.h); a word that cannot be placed is simply left out
     std::vector<uint4> kk(keep.size());
+    std::vector<uint32_t> shortq, longq;
     for (size_t q = 0; q < keep.size(); q++) {
         const size_t i = keep[q];
         uint32_t k[4] = {0, 0, 0, 0};
         const size_t len = (size_t)(offs[i + 1] - offs[i]);
         for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
         kk[q] = make_uint4(k[0], k[1], k[2], k[3]);
+        (len <= 12 ? shortq : longq).push_back((uint32_t)q);
     }
-    std::vector<uint32_t> where, homeless;
-    cuckoo_place(keep.size(), cap,
-                 [&](uint32_t q) { return word_hash(kk[q].x, kk[q].y, kk[q].z, kk[q].w); },
-                 [&](uint32_t q) { return word_hash2(kk[q].x, kk[q].y, kk[q].z, kk[q].w); }, where, &homeless);
-    std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
-    std::vector<uint32_t> syms(cap, 0);
     size_t placed = 0;
-    for (size_t q = 0; q < keep.size(); q++) {
-        if (where[q] == 0xFFFFFFFFu) continue;
-        keys[where[q]] = kk[q];
-        syms[where[q]] = T.cand_sym[keep[q]];
-        placed++;
+    auto place = [&](const std::vector<uint32_t>& qs, uint32_t& cap, std::vector<uint32_t>& where) {
+        cap = 1024;
+        while (cap < qs.size() * 5 / 2 + 16) cap <<= 1;
+        std::vector<uint32_t> homeless;
+        cuckoo_place(qs.size(), cap,
+                     [&](uint32_t j) { const uint4 k = kk[qs[j]]; return word_hash(k.x, k.y, k.z, k.w); },
+                     [&](uint32_t j) { const uint4 k = kk[qs[j]]; return word_hash2(k.x, k.y, k.z, k.w); },
+                     where, &homeless);
+    };
+    if (!shortq.empty()) {
+        uint32_t cap;
+        std::vector<uint32_t> where;
+        place(shortq, cap, where);
+        std::vector<uint4> slots(cap + 1, make_uint4(0, 0, 0, 0));
+        for (size_t j = 0; j < shortq.size(); j++) {
+            if (where[j] == 0xFFFFFFFFu) continue;
+            const uint4 k = kk[shortq[j]];
+            slots[where[j]] = make_uint4(k.x, k.y, k.z, T.cand_sym[keep[shortq[j]]]);
+            placed++;
+        }
+        HIP_TRY(c->d_word_short.reserve(slots.size()));
+        HIP_TRY(hipMemcpy(c->d_word_short.p, slots.data(), slots.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        c->dt.word_short = c->d_word_short.p;
+        c->dt.word_mask = cap - 1;
     }
-    HIP_TRY(c->d_word_keys.reserve(cap));
-    HIP_TRY(c->d_word_syms.reserve(cap));
-    HIP_TRY(hipMemcpy(c->d_word_keys.p, keys.data(), cap * sizeof(uint4), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_word_syms.p, syms.data(), cap * 4, hipMemcpyHostToDevice));
-    c->dt.word_keys = c->d_word_keys.p;
-    c->dt.word_syms = c->d_word_syms.p;
-    c->dt.word_mask = cap - 1;
+    if (!longq.empty() && c->dt.word_mask) {
+        uint32_t cap;
+        std::vector<uint32_t> where;
+        place(longq, cap, where);
+        std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
+        std::vector<uint32_t> syms(cap, 0);
+        for (size_t j = 0; j < longq.size(); j++) {
+            if (where[j] == 0xFFFFFFFFu) continue;
+            keys[where[j]] = kk[longq[j]];
+            syms[where[j]] = T.cand_sym[keep[longq[j]]];
+            placed++;
+        }
+        HIP_TRY(c->d_word_keys.reserve(cap));
+        HIP_TRY(c->d_word_syms.reserve(cap));
+        HIP_TRY(hipMemcpy(c->d_word_keys.p, keys.data(), cap * sizeof(uint4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_word_syms.p, syms.data(), cap * 4, hipMemcpyHostToDevice));
+        c->dt.word_keys = c->d_word_keys.p;
+        c->dt.word_syms = c->d_word_syms.p;
+        c->dt.wordl_mask = cap - 1;
+    }
     c->n_word_entries = (int64_t)placed;
     return HUTK_OK;
 }

@@ -48,11 +48,15 @@ struct DevTables {
     // [b1 << 8 | b2], stored as uint16 when sym16 else uint32 (SYM_NONE when unranked)
     const void* bytepair;
     int32_t sym16;  // every symbol < 0xFFF0: LDS arrays hold 16-bit symbols
-    // whole-word table (byte-encoder mode): 16 raw bytes, zero padded -> symbol of the one
-    // token the word encodes to.  word_mask == 0: no table.  Empty slot: keys[i].x == 0.
+    // whole-word tables: raw word bytes (zero padded) -> symbol of the one token the word encodes to; two-choice
+    // cuckoo tables, empty slot = all zero.  Words of 2..12 bytes: one 16-byte slot {bytes 0-3, 4-7, 8-11,
+    // symbol}, one load per candidate slot.  Words of 13..16 bytes (rare): keys and symbols in two arrays.
+    // word_mask == 0: no tables.
+    const uint4* word_short;
+    uint32_t word_mask;
     const uint4* word_keys;
     const uint32_t* word_syms;
-    uint32_t word_mask;
+    uint32_t wordl_mask;
 };
 
 // one word the tile kernel hands to the exception kernel

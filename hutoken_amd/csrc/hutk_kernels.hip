@@ -489,7 +489,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE
                 // costs one memory round trip whatever mix of words the lanes hold:
                 //   byte mode: symbol of the first byte (all a one-byte word needs)
                 //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
-                //   encodes to; two-choice cuckoo table, entries verified by this pipeline at context creation
+                //   encodes to; two-choice cuckoo tables, entries verified by this pipeline at context creation;
+                //   2..12-byte words need one 16-byte load per candidate slot
                 const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
                 uint32_t k0, k1, k2, k3;
                 {
@@ -511,20 +512,34 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE
                     else if (full == 2) { k2 &= keep; k3 = 0; }
                     else if (full == 3) { k3 &= keep; }
                 }
-                const uint32_t h1 = probe ? word_hash(k0, k1, k2, k3) & T.word_mask : 0u;
-                const uint32_t h2 = probe ? word_hash2(k0, k1, k2, k3) & T.word_mask : 0u;
-                uint4 key1 = make_uint4(0, 0, 0, 0), key2 = key1;
-                uint32_t sym1 = 0, sym2 = 0, isym = 0;
+                const bool probe_s = probe && nb <= 12, probe_l = probe && nb > 12;
+                const uint32_t h1 = probe_s ? word_hash(k0, k1, k2, 0u) & T.word_mask : 0u;
+                const uint32_t h2 = probe_s ? word_hash2(k0, k1, k2, 0u) & T.word_mask : 0u;
+                uint4 s1 = make_uint4(0, 0, 0, 0), s2 = s1, key1 = s1, key2 = s1;
+                uint32_t isym = 0, sym1 = 0, sym2 = 0;
                 if (T.word_mask) {  // uniform
-                    key1 = T.word_keys[h1];
-                    key2 = T.word_keys[h2];
-                    sym1 = T.word_syms[h1];
-                    sym2 = T.word_syms[h2];
+                    s1 = T.word_short[h1];
+                    s2 = T.word_short[h2];
+                }
+                const bool any_long = T.wordl_mask && __any(probe_l);  // a word of 13..16 bytes in this round
+                if (any_long) {
+                    const uint32_t g1 = probe_l ? word_hash(k0, k1, k2, k3) & T.wordl_mask : 0u;
+                    const uint32_t g2 = probe_l ? word_hash2(k0, k1, k2, k3) & T.wordl_mask : 0u;
+                    key1 = T.word_keys[g1];
+                    key2 = T.word_keys[g2];
+                    sym1 = T.word_syms[g1];
+                    sym2 = T.word_syms[g2];
                 }
                 if (BYTE_MODE) isym = T.item_sym[b0];
                 bool done = false;
-                if (probe) {
+                if (probe_s) {
                     // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
+                    const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2)) == 0;
+                    const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2)) == 0;
+                    done = hit1 || hit2;
+                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? s1.w : s2.w);
+                }
+                if (probe_l) {
                     const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
                     const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
                     done = hit1 || hit2;

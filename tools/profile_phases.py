@@ -27,6 +27,7 @@ for _ in range(5): run()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / 5
 print(f"{name} {n_docs} docs {len(d)/1e6:.1f} MB vocab {vocab}: {dt*1e3:.3f} ms/step  {len(d)/dt/1e9:.2f} GB/s  tile-kernel {ctx.last_timing()[0]:.3f} ms  ids {int(oo[-1])}")
+print("  tables:", ctx.table_stats())
 ctx.profile(True)
 run(); torch.cuda.synchronize()
 tb = _capi.load().hutk_debug_tile_bytes()
