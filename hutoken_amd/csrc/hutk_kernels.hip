@@ -294,7 +294,7 @@ struct TileLds {
 };
 
 template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(BYTE_MODE ? 6 : 5))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? 6 : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
     constexpr int POOL_CAP = 128 * WAVES, POOL_LONG_CAP = 48 * WAVES, POOL_LONG = 8;
