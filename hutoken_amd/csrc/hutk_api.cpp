@@ -197,7 +197,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));
     HIP_TRY(c->w_exc_sym.reserve(exc_elems));
     HIP_TRY(c->w_exc_mrg.reserve(exc_elems));
-    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 5 + 8));
+    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 6 + 8));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     HIP_TRY(c->w_counters.reserve(4));
@@ -214,6 +214,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_run_start = u + 2 * n_tiles;
     W.tile_exc_first = u + 3 * n_tiles;
     W.tile_nexc = u + 4 * n_tiles;
+    W.exc_tiles = u + 5 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
     W.scan_part = c->w_tile_i64.p + 2 * n_tiles + 2;

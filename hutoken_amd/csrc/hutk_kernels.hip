@@ -827,7 +827,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
     uint32_t exc_first = 0;
     if (lane == 0) {
-        if (n_exc) exc_first = atomicAdd(&W.counters[0], n_exc);
+        if (n_exc) {
+            exc_first = atomicAdd(&W.counters[0], n_exc);
+            W.exc_tiles[atomicAdd(&W.counters[2], 1u)] = (uint32_t)tile;  // k_gather_exc's work list
+        }
         W.tile_count[tile] = n_dense;
         W.tile_dense[tile] = n_dense;
         W.tile_run_start[tile] = 0;
@@ -1228,11 +1231,61 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(BatchArgs A, Worksp
 constexpr int GATHER_EXC_LDS = 1024;  // >= TILE_BYTES: at most one exception word per byte
 
 constexpr int GATHER_THREADS = 64;
-__global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArgs A, Workspace W) {
+// Tiles without exception words (nearly all): a plain copy, symbol -> id on the way.  One wavefront takes
+// GATHER_TILES consecutive tiles (their output is one contiguous stretch of ids_out); a workgroup per tile
+// was bound by workgroup dispatch, not by memory.
+constexpr int GATHER_TILES = 4, GATHER_WAVES = 4, GATHER_UNROLL = 5;
+template <typename RunT>
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(DevTables T, BatchArgs A, Workspace W) {
+    const int lane = threadIdx.x & 63;
+    const int64_t first = ((int64_t)blockIdx.x * GATHER_WAVES + (threadIdx.x >> 6)) * GATHER_TILES;
+    // everything is issued before anything is consumed: the metadata of all tiles, then up to
+    // GATHER_UNROLL x 64 symbols of each tile (a tile has ~250), then the stores
+    int64_t base[GATHER_TILES];
+    uint32_t dense[GATHER_TILES];
+#pragma unroll
+    for (int t = 0; t < GATHER_TILES; t++) {
+        const int64_t tile = first + t;
+        const bool ok = tile < A.n_tiles;
+        base[t] = ok ? W.tile_base[tile] : 0;
+        dense[t] = ok ? W.tile_dense[tile] : 0u;
+        if (ok && W.tile_nexc[tile]) dense[t] = 0;  // k_gather_exc
+    }
+    RunT v[GATHER_TILES][GATHER_UNROLL];
+#pragma unroll
+    for (int t = 0; t < GATHER_TILES; t++) {
+        if (base[t] + (int64_t)dense[t] > A.ids_cap) {
+            if (lane == 0) raise(A.err, HUTK_E_CAPACITY);
+            dense[t] = 0;
+        }
+        const RunT* run = reinterpret_cast<const RunT*>(W.run) + (first + t) * RUN_STRIDE;
+#pragma unroll
+        for (int j = 0; j < GATHER_UNROLL; j++) {
+            const uint32_t k = lane + 64 * j;
+            v[t][j] = k < dense[t] ? run[k] : (RunT)0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < GATHER_TILES; t++) {
+        int32_t* out = A.ids_out + base[t];
+#pragma unroll
+        for (int j = 0; j < GATHER_UNROLL; j++) {
+            const uint32_t k = lane + 64 * j;
+            if (k < dense[t]) out[k] = sym_to_id(T, (uint32_t)v[t][j]);
+        }
+        const RunT* run = reinterpret_cast<const RunT*>(W.run) + (first + t) * RUN_STRIDE;
+        for (uint32_t k = lane + 64 * GATHER_UNROLL; k < dense[t]; k += 64) out[k] = sym_to_id(T, (uint32_t)run[k]);
+    }
+}
+
+// Tiles with exception words, from the list k_tiles made: their ids are interleaved with the dense run.
+__global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
+    const uint32_t n_list = W.counters[2];
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    const int64_t tile = W.exc_tiles[li];
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
     const uint32_t nexc = W.tile_nexc[tile];
@@ -1242,12 +1295,9 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArg
     auto run_sym = [&](uint32_t k) -> uint32_t { return T.sym16 ? (uint32_t)run16[k] : run32[k]; };
     if (base + (int64_t)W.tile_count[tile] > A.ids_cap) {
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
-        return;
+        continue;
     }
-    if (nexc == 0) {
-        for (uint32_t k = tid; k < dense; k += GATHER_THREADS) A.ids_out[base + k] = sym_to_id(T, run_sym(k));
-        return;
-    }
+    __syncthreads();  // the LDS arrays are reused from the previous tile
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
     for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) e_pos[e] = recs[e].wpos;
     __syncthreads();
@@ -1276,6 +1326,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather(DevTables T, BatchArg
         if (r.tok_base < 0) continue;
         const int32_t* src = W.exc_tok + r.tok_base;
         for (uint32_t j = tid; j < r.cnt; j += GATHER_THREADS) A.ids_out[dst + j] = src[j];
+    }
     }
 }
 
@@ -1338,7 +1389,11 @@ void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
 }
 void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)a.n_tiles), dim3(GATHER_THREADS), 0, s, t, a, w);
+    const int64_t per_wg = (int64_t)GATHER_TILES * GATHER_WAVES;
+    const dim3 g((unsigned)((a.n_tiles + per_wg - 1) / per_wg)), b(64 * GATHER_WAVES);
+    if (t.sym16) hipLaunchKernelGGL(k_gather<uint16_t>, g, b, 0, s, t, a, w);
+    else hipLaunchKernelGGL(k_gather<uint32_t>, g, b, 0, s, t, a, w);
+    hipLaunchKernelGGL(k_gather_exc, dim3(1024), dim3(GATHER_THREADS), 0, s, t, a, w);
 }
 void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const unsigned g = (unsigned)((a.n_docs + 1 + 255) / 256);
