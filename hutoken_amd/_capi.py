@@ -33,8 +33,9 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_HIP
-    if build_if_missing and (not os.path.exists(path) or os.environ.get("HUTOKEN_AMD_REBUILD")):
+    # HUTOKEN_AMD_LIB: another build of the same library (tools/ab.py compares two on one GPU box)
+    path = os.environ.get("HUTOKEN_AMD_LIB") or _build.LIB_HIP
+    if path == _build.LIB_HIP and build_if_missing and (not os.path.exists(path) or os.environ.get("HUTOKEN_AMD_REBUILD")):
         _build.build_hip()
     if not os.path.exists(path):
         raise RuntimeError("hutoken_amd: native library %s is missing (run `python -m hutoken_amd.build`)" % path)

@@ -259,13 +259,19 @@ __device__ __forceinline__ uint32_t win_byte(const Win w, int k) {
     return (uint32_t)(v >> ((k & 7) * 8)) & 0xFFu;
 }
 
+// exclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (12 VALU instructions, no LDS)
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, int lane, uint32_t* total) {
+    (void)lane;
     uint32_t inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-    }
-    *total = __shfl(inc, 63, 64);
+    // inclusive scan inside each row of 16 lanes: row_shr:1, 2, 4, 8 (lanes shifted in from outside read 0)
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+    // row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2 and 3
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     return inc - v;
 }
 
