@@ -510,13 +510,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         k2 = funnel_r(q3, q2, o8);
                         k3 = funnel_r(q4, q3, o8);
                     }
-                    // zero the bytes at and beyond nb
-                    const uint32_t keep = (nb & 3) ? ((1u << (8 * (nb & 3))) - 1u) : 0xFFFFFFFFu;
-                    const int full = (nb - 1) >> 2;  // index of the last dword that holds word bytes
-                    if (full == 0) { k0 &= keep; k1 = 0; k2 = 0; k3 = 0; }
-                    else if (full == 1) { k1 &= keep; k2 = 0; k3 = 0; }
-                    else if (full == 2) { k2 &= keep; k3 = 0; }
-                    else if (full == 3) { k3 &= keep; }
+                    // zero the bytes at and beyond nb (branch-free: two 64-bit masks; nb > 16 is never probed)
+                    const uint64_t mlo = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+                    const uint64_t mhi = nb <= 8 ? 0ull : nb >= 16 ? ~0ull : ((1ull << (8 * (nb - 8))) - 1ull);
+                    k0 &= (uint32_t)mlo;
+                    k1 &= (uint32_t)(mlo >> 32);
+                    k2 &= (uint32_t)mhi;
+                    k3 &= (uint32_t)(mhi >> 32);
                 }
                 const bool probe_s = probe && nb <= 12, probe_l = probe && nb > 12;
                 const uint32_t h1 = probe_s ? word_hash(k0, k1, k2, 0u) & T.word_mask : 0u;
