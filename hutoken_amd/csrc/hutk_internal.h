@@ -33,34 +33,24 @@ static inline uint64_t pair_slot(uint32_t l, uint32_t r, uint32_t m) {
     return (uint64_t)w0 | ((uint64_t)w1 << 32);
 }
 
-// The same mixing function on host (table build) and device (lookup).
-// 24-bit multiplies (full rate on CDNA) and xor-shifts; the slot index is the LOW bits
-HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) {
+// The same mixing on host (table build) and device (lookup): 24-bit multiplies (full rate on CDNA) fold
+// (left, right) into one 32-bit word t; the two candidate slots are two different xor-shift views of t,
+// taken from the LOW bits.  (Two pairs with the same t share both slots, which a cuckoo table tolerates.)
+HUTK_HD uint32_t pair_mix(uint32_t l, uint32_t r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t h = __umul24(l, 0x9E3779u) ^ (__umul24(r, 0x85EBCBu) + 0x165667B1u);
+    return __umul24(l, 0x9E3779u) ^ (__umul24(r, 0x85EBCBu) + 0x165667B1u);
 #else
-    uint32_t h = (uint32_t)((uint64_t)(l & 0xFFFFFFu) * 0x9E3779u) ^
-                 ((uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x85EBCBu) + 0x165667B1u);
+    return (uint32_t)((uint64_t)(l & 0xFFFFFFu) * 0x9E3779u) ^
+           ((uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x85EBCBu) + 0x165667B1u);
 #endif
-    h ^= h >> 15;
-    h ^= h >> 7;
-    return h;
 }
-// Every hashed table here is a two-choice cuckoo table: a key lives in slot hash(key) or slot hash2(key)
-// and nowhere else, so a lookup is two INDEPENDENT loads issued together and never a dependent probe
-// sequence -- a wavefront pays for the slowest of its 64 lanes, and with linear probing some lane almost
-// always needed a second or third round trip.
-HUTK_HD uint32_t pair_hash2(uint32_t l, uint32_t r) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t h = (__umul24(l, 0xC2B2AEu) + 0x27D4EB2Fu) ^ __umul24(r, 0x7FEB35u);
-#else
-    uint32_t h = ((uint32_t)((uint64_t)(l & 0xFFFFFFu) * 0xC2B2AEu) + 0x27D4EB2Fu) ^
-                 (uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x7FEB35u);
-#endif
-    h ^= h >> 13;
-    h ^= h >> 6;
-    return h;
+HUTK_HD uint32_t pair_slot1(uint32_t t) {
+    t ^= t >> 15;
+    return t ^ (t >> 7);
 }
+HUTK_HD uint32_t pair_slot2(uint32_t t) { return ((t >> 13) | (t << 19)) ^ (t >> 9) ^ (t << 3); }
+HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) { return pair_slot1(pair_mix(l, r)); }
+HUTK_HD uint32_t pair_hash2(uint32_t l, uint32_t r) { return pair_slot2(pair_mix(l, r)); }
 // whole-word table: 16 raw bytes (zero padded) as four dwords
 HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     uint32_t x = k0 ^ ((k1 << 13) | (k1 >> 19)) ^ ((k2 << 7) | (k2 >> 25)) ^ ((k3 << 21) | (k3 >> 11));

@@ -51,8 +51,9 @@ namespace hutk {
 struct PairProbe { uint2 a, b; };
 __device__ __forceinline__ PairProbe pair_issue(const DevTables& T, uint32_t l, uint32_t r) {
     PairProbe p;
-    p.a = T.pair_slots[pair_hash(l, r) & T.pair_mask];
-    p.b = T.pair_slots[pair_hash2(l, r) & T.pair_mask];
+    const uint32_t t = pair_mix(l, r);
+    p.a = T.pair_slots[pair_slot1(t) & T.pair_mask];
+    p.b = T.pair_slots[pair_slot2(t) & T.pair_mask];
     return p;
 }
 __device__ __forceinline__ uint32_t pair_resolve(const PairProbe& p, uint32_t l, uint32_t r) {
