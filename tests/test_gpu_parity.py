@@ -131,6 +131,22 @@ def test_dense_word_tiles(small_byte):
         _compare(ctx, orc, [bytes([b]) for b in range(1, 256)] * 8, "one-byte-docs")
 
 
+def test_merge_pool_overflow(small_byte):
+    """More merge-loop words in a workgroup's four tiles than its pool holds (512, of which 192 long ones):
+    the rest waits in the tiles and goes through further epochs.  Words are random letter strings, so nearly
+    none is a vocabulary key and all of them need the merge loop."""
+    rng = random.Random(23)
+    def words(n_words, lo, hi):
+        return b" ".join(bytes(rng.choice(b"qxzjkvwy") for _ in range(rng.randint(lo, hi))) for _ in range(n_words))
+    docs = [words(3000, 2, 3),        # ~270 short merge words per tile
+            words(2000, 10, 14),      # ~75 long merge words per tile
+            words(1500, 2, 30),       # mixed
+            b"\n".join(words(40, 2, 20) for _ in range(60))]
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, docs, "pool")
+        _compare(ctx, orc, [words(rng.randint(0, 400), 2, 16) for _ in range(200)], "pool-many-docs")
+
+
 def test_random_text_char_mode_with_prefix(small_char):
     for k, (ctx, orc) in enumerate(small_char):
         rng = random.Random(300 + k)
