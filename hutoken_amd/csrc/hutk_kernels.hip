@@ -988,6 +988,99 @@ __device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int l
 constexpr int EXC_CHUNK = 256;                    // positions examined per step when a word end is unknown
 constexpr int EXC_WIN = 16 + EXC_CHUNK + 16;      // staged bytes per step
 
+// The same merge rule for words too long for the LDS arrays (up to MAX_WORD_BYTES units), in time
+// O(merges x chunk) instead of O(merges x n): units stay where they are (a consumed unit is marked
+// dead), and the minimum over all pairs comes from a two-level structure -- per chunk of CH units the
+// best (rank, position) key in LDS (L1r/L1p, at most 1024 chunks), the global best by a wave reduction
+// over those.  A merge touches three pair results, so three chunks are rescanned.  The survivors are
+// compacted to the front at the end.  Sg/Mg are this word's regions of the exception arrays in HBM.
+constexpr uint32_t UNIT_DEAD = 0xFFFFFFFEu;
+__device__ int64_t bpe_wave_big(const DevTables& T, HbmArr Sg, HbmArr Mg, uint32_t* L1r, uint32_t* L1p, int64_t n,
+                                int lane) {
+    const int64_t CH = (((n + EXC_LDS_UNITS - 1) / EXC_LDS_UNITS) + 63) & ~(int64_t)63;  // units per chunk
+    const int NC = (int)((n + CH - 1) / CH);                                               // <= 1024
+    for (int64_t i = lane; i < n; i += 64)
+        Mg.set(i, (i + 1 < n) ? pair_lookup(T, Sg.get(i), Sg.get(i + 1)) : SYM_NONE);
+    __syncthreads();
+    auto rescan = [&](int64_t c) {  // whole wavefront: best key of chunk c -> L1
+        const int64_t lo = c * CH, hi = (lo + CH < n) ? lo + CH : n;
+        uint64_t best = ~0ull;
+        for (int64_t i = lo + lane; i < hi; i += 64) {
+            const uint32_t m = Mg.get(i);
+            if (m != SYM_NONE) {
+                const uint64_t k = ((uint64_t)rank_of(T, m) << 32) | (uint64_t)i;
+                best = k < best ? k : best;
+            }
+        }
+        best = wave_min_u64(best);
+        if (lane == 0) {
+            L1r[c] = (uint32_t)(best >> 32);
+            L1p[c] = (uint32_t)best;
+        }
+    };
+    for (int c = 0; c < NC; c++) rescan(c);
+    __syncthreads();
+    // first live unit at or after `from` (-1: none); last live unit at or before `from` (-1: none)
+    auto next_live = [&](int64_t from) -> int64_t {
+        for (int64_t base = from; base < n; base += 64) {
+            const int64_t i = base + lane;
+            const unsigned long long bal = __ballot(i < n && Sg.get(i) != UNIT_DEAD);
+            if (bal) return base + __builtin_ctzll(bal);
+        }
+        return -1;
+    };
+    auto prev_live = [&](int64_t from) -> int64_t {
+        for (int64_t base = from; base >= 0; base -= 64) {
+            const int64_t i = base - lane;
+            const unsigned long long bal = __ballot(i >= 0 && Sg.get(i) != UNIT_DEAD);
+            if (bal) return base - __builtin_ctzll(bal);
+        }
+        return -1;
+    };
+    for (;;) {
+        uint64_t best = ~0ull;
+        for (int c = lane; c < NC; c += 64) {
+            const uint64_t k = ((uint64_t)L1r[c] << 32) | (uint64_t)L1p[c];
+            best = k < best ? k : best;
+        }
+        best = wave_min_u64(best);
+        if (best == ~0ull) break;
+        const int64_t p = (int64_t)(best & 0xFFFFFFFFull);
+        const uint32_t merged = Mg.get(p);
+        const int64_t q = next_live(p + 1);  // the unit the merge consumes (exists: the pair was a candidate)
+        const int64_t q2 = next_live(q + 1), p0 = prev_live(p - 1);
+        const uint32_t sr = q2 >= 0 ? Sg.get(q2) : 0u, sl = p0 >= 0 ? Sg.get(p0) : 0u;
+        __syncthreads();
+        if (lane == 0) {
+            Sg.set(p, merged);
+            Sg.set(q, UNIT_DEAD);
+            Mg.set(q, SYM_NONE);
+            Mg.set(p, q2 >= 0 ? pair_lookup(T, merged, sr) : SYM_NONE);
+        }
+        if (lane == 1 && p0 >= 0) Mg.set(p0, pair_lookup(T, sl, merged));
+        __syncthreads();
+        const int64_t cp = p / CH, cq = q / CH, c0 = p0 >= 0 ? p0 / CH : cp;
+        rescan(cp);
+        if (cq != cp) rescan(cq);
+        if (c0 != cp) rescan(c0);
+        __syncthreads();
+    }
+    // compaction of the survivors to the front, 64 units at a time (writes never pass the reads)
+    int64_t out = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const int64_t i = base + lane;
+        const uint32_t sym = i < n ? Sg.get(i) : UNIT_DEAD;
+        const bool live = sym != UNIT_DEAD;
+        const unsigned long long bal = __ballot(live);
+        __syncthreads();
+        if (live) Sg.set(out + __popcll(bal & ((1ull << lane) - 1ull)), sym);
+        out += __popcll(bal);
+        __syncthreads();
+    }
+    return out;
+}
+
+
 __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t Sl[EXC_LDS_UNITS];
     __shared__ uint32_t Ml[EXC_LDS_UNITS];
@@ -1129,7 +1222,7 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
         }
         __syncthreads();
 
-        const int64_t left = in_lds ? bpe_wave(T, Sl_a, Ml_a, n, lane) : bpe_wave(T, Sg_a, Mg_a, n, lane);
+        const int64_t left = in_lds ? bpe_wave(T, Sl_a, Ml_a, n, lane) : bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane);
         const int na = alone ? T.n_prefix_alone : 0;
         int32_t* out = W.exc_tok + gbase;
         for (int i = lane; i < na; i += 64) out[i] = T.prefix_alone_ids[i];

@@ -121,6 +121,33 @@ def test_long_words_exception_path(small_byte):
         _compare(ctx, orc, docs, "long")
 
 
+def test_giant_words(vg_files, oracle_mod):
+    """Words of tens of thousands of units that really merge (the two-level minimum structure of
+    bpe_wave_big), up to the reference's limit of 262144 bytes.  The oracle's quadratic specification loop
+    checks 30000 units; the largest size is checked against the compiled reference when it is present."""
+    vp, sp, kw = vg_files
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    rng = random.Random(29)
+    def blob(n):
+        parts = []
+        while sum(map(len, parts)) < n:
+            parts.append(rng.choice([b"international", b"szolg", "árvíztűrő".encode(), b"xq", b"the", b"ation"]))
+        return b"".join(parts)[:n]
+    docs = [b"a " + blob(1100) + b" b", blob(5000), b"x " + blob(30000), blob(2047) + b" " + blob(1025)]
+    _compare(ctx, orc, docs, "giant")
+    from oracle import ref
+    if ref.available():
+        big = blob(262143)
+        tok = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+        want, _err = tok.encode_bytes(b"q " + big)
+        from oracle import oracle as O
+        data, offs = O.pack([b"q " + big])
+        ids_g, oo_g, st_g, rc = ctx.encode_packed(data, offs)
+        assert rc == 0 and st_g.tolist() == [0]
+        assert ids_g.tolist() == list(want)
+
+
 def test_dense_word_tiles(small_byte):
     """Tiles packed with the shortest possible words: every byte a word (newlines, stray bytes), and
     two-byte words back to back (the most multi-unit words a tile can start)."""
