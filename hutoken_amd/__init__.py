@@ -56,10 +56,9 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
     if pattern is not None:
         raise RuntimeError("hutoken_amd: the regex `pattern` pre-token path (core.c:350-360) is outside "
                            "the MI355X encode path; initialise with pattern=None")
-    if merges_file_path is not None:
-        raise RuntimeError("hutoken_amd: the id-keyed merge path (merges file, core.c:211-337) is outside "
-                           "the MI355X encode path; initialise without a merges file")
-    new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device)
+    # merges_file_path: the id-keyed merge path (lib.c:573-663, core.c:211-337) on the same kernels
+    new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device,
+                        merges_path=merges_file_path)
     old, _ctx = _ctx, new
     if old is not None:
         old.close()
@@ -69,7 +68,13 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
 def initialize(model_or_path, *args, **kwargs):
     """hutoken.initialize (reference hutoken.py:22-120).  Local vocabulary files
     only: the Hugging Face branch needs the network and `transformers` to fetch a
-    tokenizer and is not part of this path."""
+    tokenizer and is not part of this path.
+
+    Merges file: the reference's local-file branch checks that args[6] exists and then
+    drops it (hutoken.py:30-43 never hands it to _hutoken.initialize); only its Hugging
+    Face branch passes `merges_file_path=`.  The positional form is kept as it is; the
+    keyword `merges_file_path=` (the native function's own name for it, lib.c:188-205)
+    selects the id-keyed merge path here."""
     if os.path.isfile(model_or_path):
         special_chars_file = args[0] if args else None
         merges_file = args[6] if len(args) > 6 else None
@@ -82,8 +87,11 @@ def initialize(model_or_path, *args, **kwargs):
         token_id = kwargs.get("token_id", -1)
         regex_pattern = kwargs.get("pattern", None)
         device = kwargs.get("device", int(os.environ.get("HUTOKEN_DEVICE", "-1")))
+        merges_kw = kwargs.get("merges_file_path", None)
+        if merges_kw and not os.path.isfile(merges_kw):
+            raise ValueError(f"The provided merges file '{merges_kw}' does not exist.")
         return _native_initialize(model_or_path, special_chars_file, prefix, is_byte_encoder, token_id,
-                                  regex_pattern, device=device)
+                                  regex_pattern, merges_kw, device=device)
     raise ValueError("Could not download Hugging Face tokenizer "
                      f"'{model_or_path}': hutoken_amd loads local vocabulary files only")
 

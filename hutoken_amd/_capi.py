@@ -15,7 +15,7 @@ DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
 
 # every symbol include/hutoken_amd.h declares
 EXPORTS = [
-    "hutk_ctx_create", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
+    "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
     "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
@@ -43,6 +43,10 @@ def load(build_if_missing=True):
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.hutk_ctx_create.restype = i32
     L.hutk_ctx_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, i32]
+    L.hutk_ctx_create_merges.restype = i32
+    L.hutk_ctx_create_merges.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]
+    L.hutk_uses_merges.restype = i32
+    L.hutk_uses_merges.argtypes = [vp]
     L.hutk_ctx_destroy.restype = None
     L.hutk_ctx_destroy.argtypes = [vp]
     L.hutk_last_error.restype = C.c_char_p
@@ -95,14 +99,20 @@ def raise_for(code):
 class Context:
     """Owns one hutk_ctx."""
 
-    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, device=-1):
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, device=-1, merges_path=None):
         L = load()
         h = C.c_void_p()
-        rc = L.hutk_ctx_create(C.byref(h), os.fsencode(vocab_path), os.fsencode(special_path),
-                               None if prefix is None else prefix.encode("utf-8"),
-                               1 if is_byte_encoder else 0, device)
+        rc = L.hutk_ctx_create_merges(C.byref(h), os.fsencode(vocab_path), os.fsencode(special_path),
+                                      None if prefix is None else prefix.encode("utf-8"),
+                                      1 if is_byte_encoder else 0,
+                                      None if merges_path is None else os.fsencode(merges_path), device)
         raise_for(rc)
         self._h = h
+
+    @property
+    def uses_merges(self):
+        """True when the id-keyed merge path (merges file) is in force."""
+        return bool(load().hutk_uses_merges(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -163,7 +163,19 @@ int upload_tables(hutk_ctx* c) {
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
-    if (T.has_prefix && !T.prefix_alone_syms.empty()) {
+    if (T.has_prefix && T.prefix_alone_final) {
+        // id-keyed path: the prefix as a word of its own was merged on the host (it stays string-keyed)
+        if (T.prefix_alone_syms.size() > (size_t)EXC_LDS_UNITS) return set_err(HUTK_E_UNSUPPORTED, "prefix too long");
+        HIP_TRY(c->d_prefix_alone_syms.reserve(T.prefix_alone_syms.size() + 1));
+        if (!T.prefix_alone_syms.empty()) {
+            HIP_TRY(hipMemcpy(c->d_prefix_alone_syms.p, T.prefix_alone_syms.data(), T.prefix_alone_syms.size() * 4,
+                              hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_prefix_alone.p, T.prefix_alone_ids.data(), T.prefix_alone_ids.size() * 4,
+                              hipMemcpyHostToDevice));
+        }
+        D.n_prefix_alone = (int32_t)T.prefix_alone_syms.size();
+        D.prefix_alone_syms = c->d_prefix_alone_syms.p;
+    } else if (T.has_prefix && !T.prefix_alone_syms.empty()) {
         if (T.prefix_alone_syms.size() > (size_t)EXC_LDS_UNITS)
             return set_err(HUTK_E_UNSUPPORTED, "prefix too long");
         DevBuf<uint32_t>& d_syms = c->d_prefix_alone_syms;  // in: units; out: the merged symbols
@@ -343,6 +355,11 @@ const char* hutk_last_error(void) { return g_err.c_str(); }
 
 int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_path,
                     const char* prefix, int is_byte_encoder, int device) {
+    return hutk_ctx_create_merges(out, vocab_path, special_path, prefix, is_byte_encoder, nullptr, device);
+}
+
+int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* special_path, const char* prefix,
+                           int is_byte_encoder, const char* merges_path, int device) {
     if (!out) return set_err(HUTK_E_ARG, "out is NULL");
     *out = nullptr;
     if (!vocab_path || !special_path)
@@ -351,7 +368,7 @@ int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_
                        "(special_file_path)");
     hutk_ctx* c = new (std::nothrow) hutk_ctx();
     if (!c) return set_err(HUTK_E_MEMORY, "out of memory");
-    LoadError le = load_tables(vocab_path, special_path, prefix, is_byte_encoder != 0, c->tab);
+    LoadError le = load_tables(vocab_path, special_path, prefix, is_byte_encoder != 0, merges_path, c->tab);
     if (le.code) {
         delete c;
         return set_err(le.code, le.msg);
@@ -407,6 +424,7 @@ int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs) 
 }
 
 int64_t hutk_vocab_size(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_keys : 0; }
+int hutk_uses_merges(const hutk_ctx* ctx) { return ctx && ctx->tab.id_path ? 1 : 0; }
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs : 0; }
 int hutk_device_ordinal(const hutk_ctx* ctx) { return ctx ? ctx->device : -1; }
 void hutk_set_timing(hutk_ctx* ctx, int enabled) {

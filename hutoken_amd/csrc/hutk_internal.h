@@ -154,6 +154,11 @@ struct Tables {
     bool has_prefix = false;
     std::vector<uint32_t> prefix_syms;        // units of the prefix when it is prepended to a word
     std::vector<uint32_t> prefix_alone_syms;  // units of the prefix encoded as its own word
+    // id-keyed merge path (a merges file was loaded): tables built by build_id_tables; the prefix encoded as
+    // a word of its own is then already merged on the host (it stays on the string path, core.c:421-446)
+    bool id_path = false;
+    bool prefix_alone_final = false;
+    std::vector<int32_t> prefix_alone_ids;
 };
 
 struct LoadError {
@@ -162,7 +167,8 @@ struct LoadError {
 };
 
 // hutk_loader.cpp: parse both files with the reference's quirks and build Tables.
+// merges_path: optional merges file (id-keyed merge path, reference lib.c:573-663)
 LoadError load_tables(const char* vocab_path, const char* special_path, const char* prefix,
-                      bool is_byte_encoder, Tables& out);
+                      bool is_byte_encoder, const char* merges_path, Tables& out);
 
 }  // namespace hutk

@@ -196,10 +196,376 @@ uint32_t pow2_at_least(uint64_t n) {
     return c;
 }
 
+
+// (left, right) -> merged entries into the two-choice cuckoo pair table
+LoadError finish_pair_table(Tables& T, const std::vector<uint64_t>& entries) {
+    T.n_sym = (uint32_t)T.sym_id.size();
+    if (T.n_sym >= SYM_UNK)
+        return fail(HUTK_E_UNSUPPORTED, "vocabulary too large for 20-bit symbols");
+    T.n_pairs = (int64_t)entries.size();
+    // two-choice cuckoo table at load <= 0.4; a placement failure (not seen in practice) doubles it
+    auto left_of = [&](uint32_t i) { return (uint32_t)entries[i] & 0xFFFFFu; };
+    auto right_of = [&](uint32_t i) {
+        return ((uint32_t)entries[i] >> 20) | (((uint32_t)(entries[i] >> 32) & 0xFFu) << 12);
+    };
+    uint32_t cap = pow2_at_least(entries.size() * 5 / 2 + 16);
+    std::vector<uint32_t> where;
+    for (int attempt = 0;; attempt++) {
+        if (cuckoo_place(entries.size(), cap,
+                         [&](uint32_t i) { return pair_hash(left_of(i), right_of(i)); },
+                         [&](uint32_t i) { return pair_hash2(left_of(i), right_of(i)); }, where))
+            break;
+        if (attempt == 4) return fail(HUTK_E_UNSUPPORTED, "pair table could not be built");
+        cap *= 2;
+    }
+    T.pair_mask = cap - 1;
+    T.pair_slots.assign(cap, SLOT_EMPTY);
+    for (size_t i = 0; i < entries.size(); i++) T.pair_slots[where[i]] = entries[i];
+    T.sym16 = T.n_sym < 0xFFF0u;
+    return {};
+}
+
+uint32_t host_pair_lookup(const Tables& T, uint32_t l, uint32_t r) {
+    const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
+    for (uint32_t h : {pair_hash(l, r) & T.pair_mask, pair_hash2(l, r) & T.pair_mask}) {
+        const uint64_t sl = T.pair_slots[h];
+        if (sl != SLOT_EMPTY && (uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1)
+            return (uint32_t)(sl >> 40);
+    }
+    return SYM_NONE;
+}
+
+// byte-encoder mode: direct table for the initial (byte, byte) pairs
+void finish_bytepair(Tables& T) {
+    if (!T.is_byte_encoder) return;
+    if (T.sym16) T.bytepair16.assign(65536, 0xFFFFu); else T.bytepair32.assign(65536, SYM_NONE);
+    for (int b1 = 1; b1 < 256; b1++)
+        for (int b2 = 1; b2 < 256; b2++) {
+            const uint32_t m = host_pair_lookup(T, T.item_sym[b1], T.item_sym[b2]);
+            if (m == SYM_NONE) continue;
+            if (T.sym16) T.bytepair16[(b1 << 8) | b2] = (uint16_t)m; else T.bytepair32[(b1 << 8) | b2] = m;
+        }
+}
+
+// non-byte mode: multi-byte character (packed) -> symbol
+void finish_char_table(Tables& T, std::vector<std::pair<uint32_t, uint32_t>>& chars) {
+    if (T.is_byte_encoder) {
+        T.char_slots.assign(16, SLOT_EMPTY);
+        T.char_mask = 15;
+        T.char_shift = 28;
+        return;
+    }
+    uint32_t cap = pow2_at_least(chars.size() * 2 + 16);
+    uint32_t lg = 0;
+    while ((1u << lg) < cap) lg++;
+    T.char_mask = cap - 1;
+    T.char_shift = 32 - lg;
+    T.char_slots.assign(cap, SLOT_EMPTY);
+    for (auto& c : chars) {
+        uint32_t h = char_hash(c.first) >> T.char_shift;
+        while (T.char_slots[h] != SLOT_EMPTY) h = (h + 1) & T.char_mask;
+        T.char_slots[h] = ((uint64_t)c.first << 32) | c.second;
+    }
+}
+
+
+// ------------------------------------------------------------------------
+// id-keyed merge path: a merges file was given (src/lib.c:573-663, src/core.c:211-337, 457-477)
+// ------------------------------------------------------------------------
+struct MergeRule {
+    int32_t l, r, rank, m;
+};
+
+// lib.c:573-663 with its quirks: lines come through fgets with a 10000-byte buffer (a longer line arrives in
+// pieces); a line counts when it does not start with '#' and holds a space; strtok(" ") takes the first two
+// space-separated fields; a rule whose left, right or concatenation is no vocabulary key is skipped and takes
+// no rank; an equal (left id, right id) replaces the earlier rule, rank included.  *has_merges tells whether
+// the reference would have created its merges map at all (it switches paths on that, core.c:457).
+LoadError read_merges(const char* path, const std::unordered_map<std::string, int32_t>& vocab, bool* has_merges,
+                      std::vector<MergeRule>& alive) {
+    File f(fopen(path, "r"));
+    if (!f) return fail(HUTK_E_FILE_NOT_FOUND, "Could not open merges file.");
+    std::vector<char> line(10000);  // MAX_LINE_LENGTH, lib.c:71
+    size_t line_count = 0;
+    while (fgets(line.data(), (int)line.size(), f.get()))
+        if (line[0] != '#' && strchr(line.data(), ' ') != nullptr) line_count++;
+    *has_merges = line_count > 0;
+    alive.clear();
+    if (!line_count) return {};
+    rewind(f.get());
+    std::unordered_map<uint64_t, size_t> at;  // (left id, right id) -> index into alive
+    size_t idx = 0;
+    int32_t rank = 0;
+    while (fgets(line.data(), (int)line.size(), f.get()) && idx < line_count) {
+        if (line[0] == '#') continue;
+        char* p = line.data();
+        p[strcspn(p, "\r\n")] = 0;
+        auto next_field = [&](char*& q) -> char* {  // strtok(.., " ")
+            while (*q == ' ') q++;
+            if (!*q) return nullptr;
+            char* start = q;
+            while (*q && *q != ' ') q++;
+            if (*q) *q++ = 0;
+            return start;
+        };
+        char* left = next_field(p);
+        char* right = left ? next_field(p) : nullptr;
+        if (!left || !right) continue;
+        const std::string ls(left), rs(right);
+        auto li = vocab.find(ls), ri = vocab.find(rs), mi = vocab.find(ls + rs);
+        if (li == vocab.end() || ri == vocab.end() || mi == vocab.end()) continue;
+        MergeRule nr{li->second, ri->second, rank++, mi->second};
+        idx++;
+        const uint64_t key = ((uint64_t)(uint32_t)nr.l << 32) | (uint32_t)nr.r;
+        auto it = at.find(key);
+        if (it == at.end()) {
+            at.emplace(key, alive.size());
+            alive.push_back(nr);
+        } else {
+            alive[it->second] = nr;
+        }
+    }
+    std::sort(alive.begin(), alive.end(), [](const MergeRule& a, const MergeRule& b) { return a.rank < b.rank; });
+    return {};
+}
+
+// The string-keyed merge of a few units on the host (core.c:66-209): only used for the prefix encoded as a
+// word of its own, which stays on the string path even when a merges file is loaded (core.c:421-446).
+std::vector<int32_t> host_string_bpe(std::vector<std::string> u, const std::unordered_map<std::string, int32_t>& vocab) {
+    for (;;) {
+        int64_t best = INT64_MAX;
+        size_t at = 0;
+        for (size_t i = 0; i + 1 < u.size(); i++) {
+            auto it = vocab.find(u[i] + u[i + 1]);
+            if (it == vocab.end() || it->second == -1) continue;
+            if ((int64_t)it->second < best) {
+                best = it->second;
+                at = i;
+            }
+        }
+        if (best == INT64_MAX) break;
+        u[at] += u[at + 1];
+        u.erase(u.begin() + (long)at + 1);
+    }
+    std::vector<int32_t> ids;
+    for (auto& x : u) {
+        auto it = vocab.find(x);
+        ids.push_back(it == vocab.end() ? -1 : it->second);
+    }
+    return ids;
+}
+
+// Device tables for the id-keyed path.  Tokens are ids here, so a symbol stands for an id: one symbol per
+// (id, rule that produces it), numbered in rule-rank order so that "smaller symbol" is "smaller rank" among
+// merge results exactly as on the string path, plus one "base" symbol for an id that can be an initial unit
+// or that no rule produces.  The merge kernels are the same; only the tables differ.
+LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab, const std::string special[256],
+                          const bool has_special[256], const char* prefix, bool is_byte_encoder,
+                          const std::vector<MergeRule>& alive, Tables& T) {
+    T.id_path = true;
+    auto single_char = [](const std::string& k) {
+        return !k.empty() && (size_t)lead_len((unsigned char)k[0]) == k.size();
+    };
+    // ---- symbols ----
+    std::unordered_map<int32_t, std::vector<uint32_t>> produced;  // id -> indices into alive
+    for (size_t k = 0; k < alive.size(); k++) produced[alive[k].m].push_back((uint32_t)k);
+    std::unordered_map<int32_t, bool> unit_id;  // ids a single character can start as (core.c:460-474)
+    std::vector<int32_t> ids;
+    {
+        std::unordered_map<int32_t, bool> seen;
+        for (auto& kv : vocab) {
+            if (kv.second == -1) continue;
+            if (single_char(kv.first)) unit_id[kv.second] = true;
+            if (!seen[kv.second]) {
+                seen[kv.second] = true;
+                ids.push_back(kv.second);
+            }
+        }
+        std::sort(ids.begin(), ids.end());
+    }
+    std::unordered_map<int32_t, uint32_t> base_sym;  // id -> its base symbol
+    std::vector<uint32_t> rule_sym(alive.size());    // rule (in rank order) -> symbol of its result
+    // The usual case -- ids 0..N-1, every id either a unit or the result of exactly one rule, results
+    // numbered in rule order (GPT-2 style files) -- lets the symbol BE the id, which saves the symbol -> id
+    // lookup when the ids are written.  Otherwise: base symbols first, then the rule results in rank order.
+    bool identity = !ids.empty() && ids.front() == 0 && ids.back() == (int32_t)ids.size() - 1;
+    for (size_t k = 0; k < alive.size() && identity; k++) {
+        if (k && alive[k].m <= alive[k - 1].m) identity = false;
+        if (unit_id.count(alive[k].m) || produced[alive[k].m].size() != 1) identity = false;
+    }
+    if (identity) {
+        T.sym_id.resize(ids.size());
+        for (int32_t id : ids) {
+            T.sym_id[(size_t)id] = id;
+            if (!produced.count(id)) base_sym[id] = (uint32_t)id;
+        }
+        for (size_t k = 0; k < alive.size(); k++) rule_sym[k] = (uint32_t)alive[k].m;
+    } else {
+        for (int32_t id : ids)
+            if (unit_id.count(id) || !produced.count(id)) {
+                base_sym[id] = (uint32_t)T.sym_id.size();
+                T.sym_id.push_back(id);
+            }
+        for (size_t k = 0; k < alive.size(); k++) {
+            rule_sym[k] = (uint32_t)T.sym_id.size();
+            T.sym_id.push_back(alive[k].m);
+        }
+    }
+    T.n_vocab_sym = (uint32_t)T.sym_id.size();
+    T.rank_is_sym = true;  // by construction: rule results are numbered in rank order
+    T.ident_ids = identity;
+    // symbols an id can be LIVE as inside a word: produced by a rule, or an initial unit
+    auto live_variants = [&](int32_t id, std::vector<uint32_t>& out) {
+        out.clear();
+        if (unit_id.count(id)) out.push_back(base_sym[id]);
+        auto it = produced.find(id);
+        if (it != produced.end())
+            for (uint32_t k : it->second) out.push_back(rule_sym[k]);
+    };
+    auto any_symbol = [&](int32_t id) -> uint32_t {  // for output only
+        if (id == -1) return SYM_UNK;
+        auto b = base_sym.find(id);
+        if (b != base_sym.end()) return b->second;
+        auto it = produced.find(id);
+        if (it != produced.end()) return rule_sym[it->second[0]];
+        return SYM_UNK;
+    };
+    auto unit_symbol = [&](const std::string& u) -> uint32_t {  // initial unit: vocabulary lookup of one character
+        auto it = vocab.find(u);
+        if (it == vocab.end() || it->second == -1) return SYM_UNK;
+        return base_sym[it->second];
+    };
+
+    // ---- items -> initial symbols: a replacement must be ONE character (the unit rule here is the UTF-8
+    // length alone, core.c:460-474, so a longer replacement is several units per input item) ----
+    std::string item_str[256];
+    for (int b = 1; b < 256; b++) {
+        T.item_sym[b] = SYM_UNK;
+        T.item_direct[b] = 0;
+        const bool never_leads = !is_byte_encoder && ((b >= 0x80 && b < 0xC0) || b >= 0xF8);
+        if (never_leads) continue;
+        std::string s;
+        if (has_special[b]) {
+            s = special[b];
+            if (!single_char(s))
+                return fail(HUTK_E_UNSUPPORTED,
+                            "with a merges file every special-character replacement has to be one character");
+        } else if (is_byte_encoder && b >= 0x80) {
+            s.push_back((char)(0xC0 | (b >> 6)));
+            s.push_back((char)(0x80 | (b & 0x3F)));
+        } else if (b < 0x80) {
+            s.push_back((char)b);
+        } else {
+            continue;  // multi-byte character without replacement: char table
+        }
+        item_str[b] = s;
+        T.item_sym[b] = unit_symbol(s);
+        T.item_direct[b] = 1;
+    }
+    T.item_sym[0] = SYM_UNK;
+    T.item_direct[0] = 1;
+
+    // ---- prefix ----
+    if (prefix && prefix[0]) {
+        T.has_prefix = true;
+        const std::string p(prefix);
+        for (size_t i = 0; i < p.size();) {  // prepended raw to the first word, then split by UTF-8 length
+            const size_t cl = (size_t)lead_len((unsigned char)p[i]);
+            if (i + cl > p.size()) return fail(HUTK_E_UNSUPPORTED, "prefix is not valid UTF-8");
+            T.prefix_syms.push_back(unit_symbol(p.substr(i, cl)));
+            i += cl;
+        }
+        // encoded as a word of its own: through the pretokenizer, UTF-8 units, STRING-keyed merges (core.c:421-446)
+        std::string enc;
+        for (size_t i = 0; i < p.size();) {
+            const unsigned char b = (unsigned char)p[i];
+            const size_t cl = is_byte_encoder ? 1 : (size_t)lead_len(b);
+            if (i + cl > p.size()) return fail(HUTK_E_UNSUPPORTED, "prefix is not valid UTF-8");
+            if (has_special[b]) enc += special[b];
+            else if (is_byte_encoder && b >= 0x80) {
+                enc.push_back((char)(0xC0 | (b >> 6)));
+                enc.push_back((char)(0x80 | (b & 0x3F)));
+            } else enc.append(p, i, cl);
+            i += cl;
+        }
+        std::vector<std::string> units;
+        if (!split_units(enc, false, units))
+            return fail(HUTK_E_UNSUPPORTED, "encoded prefix is not a whole number of units");
+        T.prefix_alone_final = true;
+        T.prefix_alone_ids = host_string_bpe(units, vocab);
+        for (int32_t id : T.prefix_alone_ids) T.prefix_alone_syms.push_back(any_symbol(id));
+    }
+
+    // ---- pairs: one entry per rule and per pair of live variants of its two ids ----
+    std::vector<uint64_t> entries;
+    entries.reserve(alive.size() + 16);
+    std::vector<uint32_t> lv, rv;
+    for (size_t k = 0; k < alive.size(); k++) {
+        live_variants(alive[k].l, lv);
+        live_variants(alive[k].r, rv);
+        for (uint32_t a : lv)
+            for (uint32_t b : rv) entries.push_back(pair_slot(a, b, rule_sym[k]));
+        if (entries.size() > (size_t)8 << 20)
+            return fail(HUTK_E_UNSUPPORTED, "merges file with too many rules per token id");
+    }
+    { LoadError pe = finish_pair_table(T, entries); if (pe.code) return pe; }
+    finish_bytepair(T);
+
+    // ---- whole-word table candidates: keys as raw input bytes ----
+    {
+        std::unordered_map<std::string, int> byte_of_unit;
+        bool ambiguous = false;
+        for (int b = 1; b < 256; b++) {
+            if (!T.item_direct[b]) continue;
+            auto ins = byte_of_unit.emplace(item_str[b], b);
+            if (!ins.second) ambiguous = true;
+        }
+        T.cand_off.push_back(0);
+        if (!ambiguous)
+            for (auto& kv : vocab) {
+                if (kv.second == -1) continue;
+                const std::string& k = kv.first;
+                std::string raw;
+                bool ok = true;
+                size_t n_units = 0;
+                for (size_t i = 0; i < k.size() && ok;) {
+                    const size_t cl = (size_t)lead_len((unsigned char)k[i]);
+                    if (i + cl > k.size()) { ok = false; break; }
+                    const std::string u = k.substr(i, cl);
+                    auto bt = byte_of_unit.find(u);
+                    if (bt != byte_of_unit.end()) raw.push_back((char)bt->second);
+                    else if (!is_byte_encoder && cl >= 2 && !has_special[(unsigned char)u[0]]) raw += u;
+                    else ok = false;
+                    i += cl;
+                    n_units++;
+                }
+                if (!ok || n_units > 16 || raw.size() < 2 || raw.size() > 16) continue;
+                const uint32_t sym = any_symbol(kv.second);
+                if (sym == SYM_UNK) continue;
+                T.cand_bytes.insert(T.cand_bytes.end(), raw.begin(), raw.end());
+                T.cand_off.push_back((uint32_t)T.cand_bytes.size());
+                T.cand_sym.push_back(sym);
+            }
+    }
+
+    // ---- non-byte mode: multi-byte character -> symbol ----
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> chars;
+        if (!is_byte_encoder)
+            for (auto& kv : vocab) {
+                const std::string& c = kv.first;
+                if (kv.second != -1 && c.size() >= 2 && c.size() <= 4 && single_char(c))
+                    chars.push_back({pack_char(c), base_sym[kv.second]});
+            }
+        finish_char_table(T, chars);
+    }
+    return {};
+}
+
 }  // namespace
 
 LoadError load_tables(const char* vocab_path, const char* special_path, const char* prefix,
-                      bool is_byte_encoder, Tables& T) {
+                      bool is_byte_encoder, const char* merges_path, Tables& T) {
     std::unordered_map<std::string, int32_t> vocab;
     LoadError e = read_vocab(vocab_path, vocab);
     if (e.code) return e;
@@ -211,6 +577,15 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     T = Tables();
     T.is_byte_encoder = is_byte_encoder;
     T.n_keys = (int64_t)vocab.size();
+    if (merges_path) {
+        // a merges file switches the reference to its id-keyed merge loop -- unless the file has no countable
+        // line, in which case no merges map exists and the string path below stays in force (lib.c:592, core.c:457)
+        bool has_merges = false;
+        std::vector<MergeRule> alive;
+        e = read_merges(merges_path, vocab, &has_merges, alive);
+        if (e.code) return e;
+        if (has_merges) return build_id_tables(vocab, special, has_special, prefix, is_byte_encoder, alive, T);
+    }
 
     // ---- symbols: keys in ascending id order (an id of -1 is "absent",
     // core.c:100,155,168,205-207) ----
@@ -329,51 +704,8 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
             entries.push_back(pair_slot(ls, rs, (uint32_t)i));
         }
     }
-    T.n_sym = (uint32_t)T.sym_id.size();
-    if (T.n_sym >= SYM_UNK)
-        return fail(HUTK_E_UNSUPPORTED, "vocabulary too large for 20-bit symbols");
-    T.n_pairs = (int64_t)entries.size();
-    {
-        // two-choice cuckoo table at load <= 0.4; a placement failure (not seen in practice) doubles it
-        auto left_of = [&](uint32_t i) { return (uint32_t)entries[i] & 0xFFFFFu; };
-        auto right_of = [&](uint32_t i) {
-            return ((uint32_t)entries[i] >> 20) | (((uint32_t)(entries[i] >> 32) & 0xFFu) << 12);
-        };
-        uint32_t cap = pow2_at_least(entries.size() * 5 / 2 + 16);
-        std::vector<uint32_t> where;
-        for (int attempt = 0;; attempt++) {
-            if (cuckoo_place(entries.size(), cap,
-                             [&](uint32_t i) { return pair_hash(left_of(i), right_of(i)); },
-                             [&](uint32_t i) { return pair_hash2(left_of(i), right_of(i)); }, where))
-                break;
-            if (attempt == 4) return fail(HUTK_E_UNSUPPORTED, "pair table could not be built");
-            cap *= 2;
-        }
-        T.pair_mask = cap - 1;
-        T.pair_slots.assign(cap, SLOT_EMPTY);
-        for (size_t i = 0; i < entries.size(); i++) T.pair_slots[where[i]] = entries[i];
-    }
-
-    // ---- byte-encoder mode: direct table for the initial (byte, byte) pairs ----
-    T.sym16 = T.n_sym < 0xFFF0u;
-    if (is_byte_encoder) {
-        auto host_lookup = [&](uint32_t l, uint32_t r) -> uint32_t {
-            const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
-            for (uint32_t h : {pair_hash(l, r) & T.pair_mask, pair_hash2(l, r) & T.pair_mask}) {
-                const uint64_t sl = T.pair_slots[h];
-                if (sl != SLOT_EMPTY && (uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1)
-                    return (uint32_t)(sl >> 40);
-            }
-            return SYM_NONE;
-        };
-        if (T.sym16) T.bytepair16.assign(65536, 0xFFFFu); else T.bytepair32.assign(65536, SYM_NONE);
-        for (int b1 = 1; b1 < 256; b1++)
-            for (int b2 = 1; b2 < 256; b2++) {
-                const uint32_t m = host_lookup(T.item_sym[b1], T.item_sym[b2]);
-                if (m == SYM_NONE) continue;
-                if (T.sym16) T.bytepair16[(b1 << 8) | b2] = (uint16_t)m; else T.bytepair32[(b1 << 8) | b2] = m;
-            }
-    }
+    { LoadError pe = finish_pair_table(T, entries); if (pe.code) return pe; }
+    finish_bytepair(T);
 
     // ---- keys as raw input bytes (whole-word table candidates) ----
     // A key is a candidate when every unit of it is produced by exactly one input: the single byte whose
@@ -414,28 +746,15 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     }
 
     // ---- non-byte mode: multi-byte character -> symbol ----
-    if (!is_byte_encoder) {
+    {
         std::vector<std::pair<uint32_t, uint32_t>> chars;
-        for (auto& kv : sym_of) {
-            const std::string& s = kv.first;
-            if (s.size() >= 2 && s.size() <= 4 && (size_t)lead_len((unsigned char)s[0]) == s.size())
-                chars.push_back({pack_char(s), kv.second});
-        }
-        uint32_t cap = pow2_at_least(chars.size() * 2 + 16);
-        uint32_t lg = 0;
-        while ((1u << lg) < cap) lg++;
-        T.char_mask = cap - 1;
-        T.char_shift = 32 - lg;
-        T.char_slots.assign(cap, SLOT_EMPTY);
-        for (auto& c : chars) {
-            uint32_t h = char_hash(c.first) >> T.char_shift;
-            while (T.char_slots[h] != SLOT_EMPTY) h = (h + 1) & T.char_mask;
-            T.char_slots[h] = ((uint64_t)c.first << 32) | c.second;
-        }
-    } else {
-        T.char_slots.assign(16, SLOT_EMPTY);
-        T.char_mask = 15;
-        T.char_shift = 28;
+        if (!is_byte_encoder)
+            for (auto& kv : sym_of) {
+                const std::string& s = kv.first;
+                if (s.size() >= 2 && s.size() <= 4 && (size_t)lead_len((unsigned char)s[0]) == s.size())
+                    chars.push_back({pack_char(s), kv.second});
+            }
+        finish_char_table(T, chars);
     }
     return {};
 }

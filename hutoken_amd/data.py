@@ -12,7 +12,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _DATA = os.path.join(_ROOT, "data")
 
 VOCABS = {
-    "VG": dict(vocab="vg50257_vocab.txt", special="vg50257_special.txt",
+    "VG": dict(vocab="vg50257_vocab.txt", special="vg50257_special.txt", merges="vg50257_merges.txt",
                kwargs=dict(prefix=None, is_byte_encoder=True)),
     "VL": dict(vocab="vl32000_vocab.txt", special="vl32000_special.txt",
                kwargs=dict(prefix="▁", is_byte_encoder=False)),
@@ -28,24 +28,34 @@ def _sums():
     return out
 
 
-def vocab_files(name, cache_dir=None):
-    """Unpack vocabulary `name` -> (vocab_path, special_path, initialize kwargs)."""
-    spec = VOCABS[name]
+def _unpacked(fname, cache_dir=None):
+    """data/<fname>.gz unpacked into a per-user cache directory, checked against data/SHA256SUMS."""
     cache_dir = cache_dir or os.path.join(tempfile.gettempdir(), "hutoken_amd_data_%d" % os.getuid())
     os.makedirs(cache_dir, exist_ok=True)
-    vpath = os.path.join(cache_dir, spec["vocab"])
-    want = _sums()[spec["vocab"]]
+    vpath = os.path.join(cache_dir, fname)
+    want = _sums()[fname]
     ok = False
     if os.path.exists(vpath):
         with open(vpath, "rb") as f:
             ok = hashlib.sha256(f.read()).hexdigest() == want
     if not ok:
-        with gzip.open(os.path.join(_DATA, spec["vocab"] + ".gz"), "rb") as f:
+        with gzip.open(os.path.join(_DATA, fname + ".gz"), "rb") as f:
             raw = f.read()
         if hashlib.sha256(raw).hexdigest() != want:
-            raise RuntimeError("data/%s.gz does not match data/SHA256SUMS" % spec["vocab"])
+            raise RuntimeError("data/%s.gz does not match data/SHA256SUMS" % fname)
         tmp = vpath + ".tmp%d" % os.getpid()
         with open(tmp, "wb") as f:
             f.write(raw)
         os.replace(tmp, vpath)
-    return vpath, os.path.join(_DATA, spec["special"]), dict(spec["kwargs"])
+    return vpath
+
+
+def vocab_files(name, cache_dir=None):
+    """Unpack vocabulary `name` -> (vocab_path, special_path, initialize kwargs)."""
+    spec = VOCABS[name]
+    return _unpacked(spec["vocab"], cache_dir), os.path.join(_DATA, spec["special"]), dict(spec["kwargs"])
+
+
+def merges_file(name, cache_dir=None):
+    """Unpack the merges.txt of vocabulary `name` (id-keyed merge path) -> path."""
+    return _unpacked(VOCABS[name]["merges"], cache_dir)

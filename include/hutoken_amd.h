@@ -54,11 +54,25 @@ enum {
  * is_byte_encoder, ...) for the encode direction: src/lib.c:185-571
  * (initialize_context 128-183, vocab loader 243-388, special-character loader
  * 460-571) and struct EncodeContext (include/hutoken/taskqueue.h:16-25).
- * The decode tables, the AC automaton, the regex pattern and the merges file are
- * outside this path.  `device` is a HIP device ordinal, or -1 for the current
+ * The decode tables, the AC automaton and the regex pattern are outside this
+ * path.  `device` is a HIP device ordinal, or -1 for the current
  * device.  On failure *out is NULL and hutk_last_error() holds the message. */
 int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_path,
                     const char* prefix, int is_byte_encoder, int device);
+
+/* The same with _hutoken.initialize's `merges_file_path` (src/lib.c:573-663): when
+ * the file holds at least one countable line the context encodes with the
+ * reference's ID-KEYED merge loop (bpe_encode_arena_ids, src/core.c:211-337; unit
+ * split and id lookup of src/core.c:457-477): rank = line order among the rules
+ * whose left, right and concatenation are vocabulary keys, result = the id of the
+ * concatenation, a repeated (left id, right id) keeps its last rule.  A file with
+ * no countable line (empty, comments only) leaves the string-keyed path in force,
+ * as in the reference.  merges_path == NULL is hutk_ctx_create.
+ * HUTK_E_UNSUPPORTED: a special-character replacement of more than one character
+ * (several units per input item on this path). */
+int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* special_path,
+                           const char* prefix, int is_byte_encoder, const char* merges_path,
+                           int device);
 
 /* The reference never frees its contexts (lib.c:129-155); this one can be. */
 void hutk_ctx_destroy(hutk_ctx* ctx);
@@ -105,6 +119,7 @@ int hutk_encode(hutk_ctx* ctx, const uint8_t* text, int64_t len, int32_t* ids_ou
 /* Introspection (tests, bench). */
 int64_t hutk_vocab_size(const hutk_ctx* ctx);      /* distinct keys loaded */
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx);
+int hutk_uses_merges(const hutk_ctx* ctx);         /* 1: the id-keyed merge path is in force */
 int hutk_device_ordinal(const hutk_ctx* ctx);
 /* out8: distinct keys, vocabulary symbols, symbols, pair entries, pair slots,
  * rank_is_sym, ident_ids, whole-word table entries.  Passing device = -2 to hutk_ctx_create

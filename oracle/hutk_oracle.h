@@ -33,6 +33,12 @@ hto_ctx* hto_create(const char* vocab_path, const char* special_path,
                     char* err, size_t errcap);
 void hto_destroy(hto_ctx* c);
 
+/* merges file (lib.c:573-663): switches the context to the id-keyed merge path
+ * (core.c:211-337, 457-477) when the file has at least one countable line */
+int hto_load_merges(hto_ctx* c, const char* path, char* err, size_t errcap);
+int hto_has_merges(const hto_ctx* c);
+uint64_t hto_rule_count(const hto_ctx* c);
+
 uint64_t hto_vocab_count(const hto_ctx* c);
 int hto_vocab_lookup(const hto_ctx* c, const uint8_t* key, size_t len,
                      int32_t* id);

@@ -40,6 +40,12 @@ def lib():
         L.hto_create.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int,
                                  C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.hto_destroy.argtypes = [C.c_void_p]
+        L.hto_load_merges.restype = C.c_int
+        L.hto_load_merges.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.hto_has_merges.restype = C.c_int
+        L.hto_has_merges.argtypes = [C.c_void_p]
+        L.hto_rule_count.restype = C.c_uint64
+        L.hto_rule_count.argtypes = [C.c_void_p]
         L.hto_vocab_count.restype = C.c_uint64
         L.hto_vocab_count.argtypes = [C.c_void_p]
         L.hto_vocab_lookup.restype = C.c_int
@@ -87,7 +93,7 @@ def pack(texts):
 
 
 class Oracle:
-    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False):
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, merges_path=None):
         L = lib()
         kind = C.c_int(0)
         err = C.create_string_buffer(256)
@@ -96,6 +102,18 @@ class Oracle:
                                1 if is_byte_encoder else 0, C.byref(kind), err, 256)
         if not self._h:
             raise _ERR_KIND.get(kind.value, RuntimeError)(err.value.decode())
+        if merges_path is not None:  # the id-keyed merge path (lib.c:573-663)
+            rc = L.hto_load_merges(self._h, os.fsencode(merges_path), err, 256)
+            if rc:
+                raise _ERR_KIND.get(rc, RuntimeError)(err.value.decode())
+
+    @property
+    def has_merges(self):
+        return bool(lib().hto_has_merges(self._h))
+
+    @property
+    def rule_count(self):
+        return lib().hto_rule_count(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

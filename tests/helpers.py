@@ -81,6 +81,54 @@ def random_char_vocab(seed, n_merges=300, drop_chars=""):
     return entries, vf.llama_special_mapping()
 
 
+def random_merges_text(entries, seed, keep=0.85, noise=True):
+    """A merges.txt for the id-keyed merge path (reference lib.c:573-663): every split of a vocabulary key
+    into two vocabulary keys is a possible rule; a random subset in random order (so rank != id order), plus
+    the lines the loader has to cope with: comments, lines without a space, runs of spaces, rules with
+    unknown tokens (skipped, take no rank), a repeated pair (the later line and rank win), CRLF endings."""
+    rng = random.Random(seed)
+    keys = {}
+    for k, i in entries:
+        keys[k] = i
+    rules = []
+    for k in keys:
+        try:
+            txt = k.decode("utf-8")
+        except UnicodeDecodeError:
+            continue
+        for cut in range(1, len(txt)):
+            a, b = txt[:cut].encode("utf-8"), txt[cut:].encode("utf-8")
+            if a in keys and b in keys and b" " not in k:
+                rules.append((a, b))
+    rng.shuffle(rules)
+    rules = rules[: int(len(rules) * keep)]
+    lines = ["#version: 0.2"]
+    for a, b in rules:
+        sep = " " if not noise or rng.random() < 0.9 else "   "
+        end = "" if not noise or rng.random() < 0.9 else "\r"
+        lines.append(a.decode("utf-8") + sep + b.decode("utf-8") + end)
+        if noise:
+            r = rng.random()
+            if r < 0.03:
+                lines.append("# a comment with a space")
+            elif r < 0.06:
+                lines.append("nospacehere")
+            elif r < 0.09:
+                lines.append("zzqx notinvocabq")
+            elif r < 0.12 and len(lines) > 5:
+                lines.append(rng.choice(lines[1:]))  # an earlier line again
+            elif r < 0.13:
+                lines.append(a.decode("utf-8") + " ")  # right half missing
+    return "\n".join(lines) + "\n"
+
+
+def write_merges(tmpdir, name, text):
+    mp = os.path.join(str(tmpdir), name + "_merges.txt")
+    with open(mp, "w", encoding="utf-8", newline="") as f:
+        f.write(text)
+    return mp
+
+
 def write_vocab(tmpdir, name, entries, special):
     vp = os.path.join(str(tmpdir), name + "_vocab.txt")
     sp = os.path.join(str(tmpdir), name + "_special.txt")

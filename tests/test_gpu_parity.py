@@ -11,9 +11,9 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _ctx(vp, sp, prefix, is_byte):
+def _ctx(vp, sp, prefix, is_byte, merges=None):
     from hutoken_amd import _capi
-    return _capi.Context(vp, sp, prefix, is_byte)
+    return _capi.Context(vp, sp, prefix, is_byte, merges_path=merges)
 
 
 def _compare(ctx, orc, docs, tag=""):
@@ -242,6 +242,66 @@ def test_vl_vocab_on_corpora(vl_files, oracle_mod):
         data, offs = synth.corpus(name, n)
         ids_o, oo_o, _ = orc.encode_packed(data, offs, num_threads=8)
         ids_g, oo_g, st, rc = ctx.encode_packed(data, offs)
+        assert rc == 0
+        assert np.array_equal(oo_o, oo_g), name
+        assert np.array_equal(ids_o, ids_g), name
+
+
+def test_merges_path_random_vocabularies(tmp_path, oracle_mod):
+    """The id-keyed merge path (a merges file; reference core.c:211-337, 457-477, lib.c:573-663): rule order
+    unrelated to id order, skipped rules, repeated pairs, shuffled and duplicate ids, with and without a
+    prefix; the same kernels on different tables."""
+    for seed, proper, dup, prefix in [(1, True, False, None), (2, False, False, None), (3, True, True, None),
+                                      (4, True, False, "Ġ"), (5, False, False, "ab")]:
+        ents, sp = H.random_byte_vocab(seed, n_merges=500, proper=proper, dup_ids=dup)
+        vp, spath = H.write_vocab(tmp_path, f"m{seed}", ents, sp)
+        mp = H.write_merges(tmp_path, f"m{seed}", H.random_merges_text(ents, seed * 3, keep=0.8))
+        ctx = _ctx(vp, spath, prefix, True, mp)
+        orc = oracle_mod.Oracle(vp, spath, prefix, True, mp)
+        assert ctx.uses_merges and orc.has_merges
+        rng = random.Random(400 + seed)
+        docs = [H.random_text(rng, max_words=40).encode("utf-8") for _ in range(2500)]
+        docs += [H.random_bytes_text(rng, rng.randint(0, 60)) for _ in range(1500)]
+        docs += [b"", b" ", b"a", b" a", bytes(rng.choice(b"etaoin") for _ in range(700)), b"x" * 3000]
+        _compare(ctx, orc, docs, f"merges{seed}")
+    # a file without a countable line leaves the string path in force (lib.c:592)
+    ents, sp = H.random_byte_vocab(7, n_merges=300)
+    vp, spath = H.write_vocab(tmp_path, "m7", ents, sp)
+    mp = H.write_merges(tmp_path, "m7", "#version: 0.2\n")
+    ctx = _ctx(vp, spath, None, True, mp)
+    assert not ctx.uses_merges
+    _compare(ctx, oracle_mod.Oracle(vp, spath, None, True, mp), [b"hello world", b"  x"], "merges-empty")
+
+
+def test_merges_path_char_mode(tmp_path, oracle_mod):
+    """Non-byte mode on the id-keyed path: one-character replacements work; the byte-fallback literals of a
+    Llama-style special file are several units per input byte there and are refused at load time."""
+    ents, _sp = H.random_char_vocab(1, n_merges=400)
+    vp, spath = H.write_vocab(tmp_path, "mc1", ents, {32: "▁"})
+    mp = H.write_merges(tmp_path, "mc1", H.random_merges_text(ents, 5))
+    ctx = _ctx(vp, spath, "▁", False, mp)
+    orc = oracle_mod.Oracle(vp, spath, "▁", False, mp)
+    rng = random.Random(501)
+    docs = [H.random_text(rng, max_words=30).replace("\t", " ").replace("\n", " ").replace("\r", " ").encode("utf-8")
+            for _ in range(3000)]
+    _compare(ctx, orc, docs + [b"", b" ", b"a", b" a"], "merges-char")
+    from hutoken_amd import _capi
+    ents2, sp2 = H.random_char_vocab(2, n_merges=100)
+    vp2, spath2 = H.write_vocab(tmp_path, "mc2", ents2, sp2)
+    with pytest.raises(Exception, match="one character"):
+        _capi.Context(vp2, spath2, "▁", False, merges_path=mp)
+
+
+def test_merges_path_vg_on_corpora(vg_files, oracle_mod):
+    from hutoken_amd import data, synth
+    vp, sp, kw = vg_files
+    mp = data.merges_file("VG")
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
+    for name, n in [("C3", 3000), ("C2", 2000)]:
+        d, o = synth.corpus(name, n)
+        ids_o, oo_o, _ = orc.encode_packed(d, o, num_threads=8)
+        ids_g, oo_g, st, rc = ctx.encode_packed(d, o)
         assert rc == 0
         assert np.array_equal(oo_o, oo_g), name
         assert np.array_equal(ids_o, ids_g), name

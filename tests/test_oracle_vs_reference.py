@@ -37,6 +37,56 @@ def test_char_mode_with_prefix(tmp_path, oracle_mod):
             assert orc.encode(t) == r.encode(t), repr(t)
 
 
+def test_merges_path_byte_mode(tmp_path, oracle_mod):
+    """The id-keyed merge path (merges file; core.c:211-337, 457-477; lib.c:573-663)."""
+    for seed in range(5):
+        ents, sp = H.random_byte_vocab(seed, n_merges=400, proper=seed % 2 == 0, dup_ids=seed == 3)
+        vp, spath = H.write_vocab(tmp_path, f"mb{seed}", ents, sp)
+        mp = H.write_merges(tmp_path, f"mb{seed}", H.random_merges_text(ents, seed, keep=0.6 if seed == 4 else 0.9))
+        orc = oracle_mod.Oracle(vp, spath, None, True, mp)
+        r = ref.RefTokenizer(vp, spath, None, True, mp)
+        assert orc.has_merges
+        rng = random.Random(seed * 91)
+        for _ in range(600):
+            t = H.random_text(rng)
+            assert orc.encode(t) == r.encode(t), repr(t)
+        for _ in range(400):
+            b = H.random_bytes_text(rng, rng.randint(0, 20))
+            assert orc.encode_bytes(b)[0] == r.encode_bytes(b)[0], repr(b)
+
+
+def test_merges_path_char_mode_with_prefix(tmp_path, oracle_mod):
+    """Non-byte mode: "<0xHH>" replacements are split per character on this path (core.c:460-474), the
+    prefix encoded on its own still takes the string path (core.c:421-446)."""
+    for seed in range(3):
+        ents, sp = H.random_char_vocab(seed, n_merges=400, drop_chars="qző漢" if seed % 2 else "")
+        vp, spath = H.write_vocab(tmp_path, f"mc{seed}", ents, sp)
+        mp = H.write_merges(tmp_path, f"mc{seed}", H.random_merges_text(ents, seed + 10))
+        orc = oracle_mod.Oracle(vp, spath, "▁", False, mp)
+        r = ref.RefTokenizer(vp, spath, "▁", False, mp)
+        rng = random.Random(seed * 57)
+        for _ in range(800):
+            t = H.random_text(rng)
+            assert orc.encode(t) == r.encode(t), repr(t)
+
+
+def test_merges_file_degenerate_forms(tmp_path, oracle_mod):
+    """No countable line: the string path stays in force.  Countable lines but no valid rule: the id path
+    with no merges at all (every character its own id)."""
+    ents, sp = H.random_byte_vocab(9, n_merges=200)
+    vp, spath = H.write_vocab(tmp_path, "md", ents, sp)
+    texts = ["hello world", "árvíztűrő tükörfúrógép", " a  b", "", "x"]
+    for name, body in [("empty", ""), ("hdr", "#version: 0.2\n"), ("nosp", "abc\ndef\n"),
+                       ("junk", "zz yy\nqq ww\n"), ("half", "a \n")]:
+        mp = H.write_merges(tmp_path, name, body)
+        orc = oracle_mod.Oracle(vp, spath, None, True, mp)
+        r = ref.RefTokenizer(vp, spath, None, True, mp)
+        for t in texts:
+            assert orc.encode(t) == r.encode(t), (name, t)
+    with pytest.raises(FileNotFoundError):
+        oracle_mod.Oracle(vp, spath, None, True, str(tmp_path / "missing.txt"))
+
+
 def test_batch_threads_and_word_too_large(tmp_path, oracle_mod):
     ents, sp = H.random_byte_vocab(9, n_merges=100)
     vp, spath = H.write_vocab(tmp_path, "t", ents, sp)

@@ -6,6 +6,7 @@ are committed).  Test/bench data infrastructure, not the product path.
       learned by tools/train_vocab.cpp on 125000 documents (64 MB) of corpus C3
       (generator seed 0x564f4347), then <|endoftext|>.  ids = merge order.
       is_byte_encoder=True, no prefix.  Special file = the 68 remapped bytes.
+      vg50257_merges.txt: the 50000 rules in merges.txt form (id-keyed merge path).
   VL  SentencePiece/Llama shape, 32000 lines: <unk>, <s>, </s>, 256 byte-fallback
       literals <0xHH>, the base characters, then merges learned in "chars" mode
       on 60000 documents of corpus C5 (seed 0x564f434c).
@@ -52,7 +53,8 @@ def main():
 
     # ---- VG ----
     mg = os.path.join(tmp, "vg.txt")
-    subprocess.check_call([exe, "3", "0x564f4347", "125000", "50000", mg])
+    mg_pairs = os.path.join(tmp, "vg_pairs.txt")
+    subprocess.check_call([exe, "3", "0x564f4347", "125000", "50000", mg, "bytes", mg_pairs])
     t = vf.bytes_to_unicode()
     lines = []
     idx = 0
@@ -70,6 +72,14 @@ def main():
     with open(os.path.join(DATA, "vg50257_special.txt"), "w", encoding="utf-8") as f:
         f.write(sp)
     sums["vg50257_special.txt"] = hashlib.sha256(sp.encode("utf-8")).hexdigest()
+    # the merge rules in GPT-2's merges.txt format (visible characters, one "left right" per line, rank =
+    # line order): input of the id-keyed merge path (reference core.c:211-337, lib.c:573-663)
+    mtext = "#version: 0.2\n"
+    for ln in open(mg_pairs):
+        l, r = ln.split()
+        mtext += (vf.encode_visible(bytes.fromhex(l), t).decode("utf-8") + " " +
+                  vf.encode_visible(bytes.fromhex(r), t).decode("utf-8") + "\n")
+    sums["vg50257_merges.txt"] = write_gz(os.path.join(DATA, "vg50257_merges.txt.gz"), mtext)
 
     # ---- VL ----
     ml = os.path.join(tmp, "vl.txt")

@@ -2,7 +2,7 @@
 // GPT-2-shaped synthetic vocabulary data/vg50257_*.txt.gz (test/bench data
 // infrastructure, not part of the product path).
 //
-//   train_vocab <kind 2|3|5> <seed> <n_docs> <n_merges> <out.txt> [bytes|chars]
+//   train_vocab <kind 2|3|5> <seed> <n_docs> <n_merges> <out.txt> [bytes|chars] [pairs_out.txt]
 //
 // "bytes" (default): initial symbols are the 256 byte values (GPT-2 shape).
 // "chars": ' ' is rewritten to U+2581 and initial symbols are whole UTF-8
@@ -56,6 +56,8 @@ int main(int argc, char** argv) {
     int64_t n_docs = atoll(argv[3]);
     int n_merges = atoi(argv[4]);
     bool chars = argc > 6 && !strcmp(argv[6], "chars");
+    // optional 8th argument: file that receives one "LEFTHEX RIGHTHEX" line per merge
+    FILE* pairs_out = argc > 7 ? fopen(argv[7], "w") : nullptr;
 
     std::vector<int64_t> offs(n_docs + 1);
     uint8_t* bytes = nullptr;
@@ -168,6 +170,12 @@ int main(int argc, char** argv) {
         tok.push_back(tok[a] + tok[b]);
         for (unsigned char c : tok.back()) fprintf(out, "%02X", c);
         fputc('\n', out);
+        if (pairs_out) {  // the rule itself, for a merges file: left and right halves in hex
+            for (unsigned char c : tok[a]) fprintf(pairs_out, "%02X", c);
+            fputc(' ', pairs_out);
+            for (unsigned char c : tok[b]) fprintf(pairs_out, "%02X", c);
+            fputc('\n', pairs_out);
+        }
         done++;
         std::vector<int32_t> occ;
         occ.swap(where[top.pair]);
@@ -212,6 +220,7 @@ int main(int argc, char** argv) {
         if (done % 5000 == 0) fprintf(stderr, "merges: %d (last count %lld)\n", done, (long long)top.count);
     }
     fclose(out);
+    if (pairs_out) fclose(pairs_out);
     fprintf(stderr, "done: %d merges\n", done);
     return done == n_merges ? 0 : 3;
 }
