@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores):
+def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores, mp=None):
     """Times the CPU path on the first n_sample documents of the workload."""
     import numpy as np
     from hutoken_amd import synth
@@ -47,7 +47,7 @@ def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores):
         from oracle import ref
         if ref.available():
             docs = synth.docs_as_str(data, offs)
-            tok = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+            tok = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
             tok.batch_encode(docs[:1000], cores)
             t = time.perf_counter()
             res = tok.batch_encode(docs, cores)
@@ -60,7 +60,7 @@ def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores):
     except Exception as e:  # fall through to the port
         out["reference_error"] = repr(e)
     from oracle import oracle as O
-    orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
     orc.encode_packed(data[: int(offs[1000])], offs[:1001], cores)
     t = time.perf_counter()
     ids, oo, st = orc.encode_packed(data, offs, cores)
@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--cpu-docs", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--merges", action="store_true",
+                    help="secondary configuration: the id-keyed merge path (VG with its merges file, SURVEY 8 f-1); "
+                         "the default and BASELINE metric is the string-keyed path")
     args = ap.parse_args()
 
     import numpy as np
@@ -119,7 +122,8 @@ def main():
 
     from hutoken_amd import _capi, data as hdata, synth
     vp, sp, kw = hdata.vocab_files("VG")
-    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=local_rank)
+    mp = hdata.merges_file("VG") if args.merges else None
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=local_rank, merges_path=mp)
 
     n_docs = args.docs or synth.KINDS[args.corpus][2]
     cores = os.cpu_count() or 1
@@ -179,7 +183,7 @@ def main():
     verified = None
     if not args.no_verify:
         from oracle import oracle as O
-        orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+        orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
         k = min(2000, n_docs)
         ids_o, oo_o, _ = orc.encode_packed(data[: int(offs[k])], offs[: k + 1], min(cores, 8))
         oo_g = d_oo[: k + 1].cpu().numpy()
@@ -203,7 +207,9 @@ def main():
             "config": {"workload": f"{args.corpus}: {n_docs} synthetic docs per GPU "
                                    f"({n_bytes / 1e6:.1f} MB, mean {n_bytes / n_docs:.0f} B, "
                                    f"{'mixed UTF-8' if args.corpus != 'C2' else 'ASCII'}), "
-                                   "vocab VG (GPT-2 shape, 50257 entries), device-resident packed I/O",
+                                   "vocab VG (GPT-2 shape, 50257 entries)"
+                                   f"{', id-keyed merge path (merges file)' if args.merges else ''}, "
+                                   "device-resident packed I/O",
                        "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "ids_per_gpu": n_ids,
                        "parallelism": f"documents sharded over {world} GPU(s), all-gather of id totals"},
             "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2),
@@ -214,7 +220,7 @@ def main():
             "gen_s": round(t_gen, 2),
         }
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(vp, sp, kw, args.corpus, min(args.cpu_docs, n_docs), cores)
+            line["cpu_baseline"] = cpu_baseline(vp, sp, kw, args.corpus, min(args.cpu_docs, n_docs), cores, mp)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

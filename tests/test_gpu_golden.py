@@ -27,9 +27,9 @@ def load(name):
         return json.load(f)
 
 
-def ctx_for(vp, sp, prefix, is_byte):
+def ctx_for(vp, sp, prefix, is_byte, merges=None):
     from hutoken_amd import _capi
-    return _capi.Context(vp, sp, prefix, is_byte)
+    return _capi.Context(vp, sp, prefix, is_byte, merges_path=merges)
 
 
 def encode_texts(ctx, texts):
@@ -173,3 +173,27 @@ def test_errors_and_limits(tmp_path, oracle_mod):
     assert st_o.tolist() == [0, 0, 1, 0] == st_g.tolist()
     assert np.array_equal(oo_o, oo_g) and np.array_equal(ids_o, ids_g)
     assert ids_g[oo_g[2]:oo_g[3]].tolist() == orc.encode(b"hi")
+
+
+def test_g5_merges_path(tmp_path):
+    """The id-keyed merge path (merges file) against the reference's outputs."""
+    from hutoken_amd import data, synth
+    for g in load("g5_merges_path.json"):
+        if g.get("vocab") == "VG+merges":
+            vp, sp, kw = data.vocab_files("VG")
+            ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"], data.merges_file("VG"))
+            d, o = synth.corpus(g["corpus"], g["n_docs"])
+            ids, oo, st, rc = ctx.encode_packed(d, o)
+            assert rc == 0
+            res = [ids[oo[i]:oo[i + 1]].tolist() for i in range(g["n_docs"])]
+        else:
+            ents, sp = H.random_byte_vocab(g["seed"], n_merges=2000, proper=g["proper"], dup_ids=g["dup_ids"])
+            vp, spath = H.write_vocab(tmp_path, "g5_%d" % g["seed"], ents, sp)
+            mp = H.write_merges(tmp_path, "g5_%d" % g["seed"], H.random_merges_text(ents, g["seed"] * 3, keep=0.8))
+            ctx = ctx_for(vp, spath, g["prefix"], True, mp)
+            assert ctx.uses_merges
+            rng = random.Random(g["seed"] * 1000)
+            res = encode_texts(ctx, [H.random_text(rng, max_words=30) for _ in range(1500)])
+        assert res[:len(g["first"])] == g["first"]
+        assert sum(len(x) for x in res) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]

@@ -106,6 +106,37 @@ def test_table_shapes(vg_files, vl_files):
     assert st["n_keys"] == 32000 and st["n_sym"] >= 32000
 
 
+def test_merges_file_loader(tmp_path, special, vg_files):
+    """Merges file -> id-keyed tables (lib.c:573-663), host-only context."""
+    from hutoken_amd import data
+    vp, sp, kw = vg_files
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2, merges_path=data.merges_file("VG"))
+    st = ctx.table_stats()
+    assert ctx.uses_merges
+    assert st["n_pairs"] == 50000 and st["n_sym"] == 50257  # one symbol per id: 16-bit symbols stay possible
+    assert st["rank_is_sym"] == 1 and st["ident_ids"] == 1  # GPT-2 style file: the symbol is the id
+    # rule order unrelated to ids, skipped and repeated rules: symbols are renumbered, not the ids
+    ents, spm = H.random_byte_vocab(31, n_merges=300, proper=False)
+    vp2, sp2 = H.write_vocab(tmp_path, "m", ents, spm)
+    mp = H.write_merges(tmp_path, "m", H.random_merges_text(ents, 5))
+    ctx = _capi.Context(vp2, sp2, None, True, device=-2, merges_path=mp)
+    assert ctx.uses_merges and ctx.table_stats()["rank_is_sym"] == 1
+    # no countable line: the string path stays (the reference creates no merges map, lib.c:592)
+    for body in ["", "#version: 0.2\n", "nospace\n"]:
+        ctx = _capi.Context(vp2, sp2, None, True, device=-2, merges_path=write(tmp_path, "e.txt", body))
+        assert not ctx.uses_merges
+    # countable lines without a single valid rule: the id path with no rule at all
+    ctx = _capi.Context(vp2, sp2, None, True, device=-2, merges_path=write(tmp_path, "j.txt", "zz yy\n"))
+    assert ctx.uses_merges and ctx.table_stats()["n_pairs"] == 0
+    with pytest.raises(FileNotFoundError, match="Could not open merges file."):
+        _capi.Context(vp2, sp2, None, True, device=-2, merges_path=os.path.join(str(tmp_path), "absent.txt"))
+    # a replacement of several characters is several units per input byte on this path: refused
+    centries, cspecial = H.random_char_vocab(2, n_merges=50)
+    vp3, sp3 = H.write_vocab(tmp_path, "c", centries, cspecial)
+    with pytest.raises(Exception, match="one character"):
+        _capi.Context(vp3, sp3, "▁", False, device=-2, merges_path=mp)
+
+
 def test_unsupported_special_files_are_rejected_loudly(tmp_path):
     vp = write(tmp_path, "v.txt", "0x61 == 0\n")
     for text in (b"97 == Alpha\n",      # more than one unit per replacement

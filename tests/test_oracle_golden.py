@@ -81,3 +81,26 @@ def test_corpora(fixture, vocab, oracle_mod):
         assert res[:len(g["first"])] == g["first"]
         assert int(oo[-1]) == g["n_ids"]
         assert sha_ids(res) == g["sha256"]
+
+
+def test_g5_merges_path(tmp_path, oracle_mod):
+    """The id-keyed merge path (merges file) against the reference's outputs."""
+    from hutoken_amd import data, synth
+    for g in load("g5_merges_path.json"):
+        if g.get("vocab") == "VG+merges":
+            vp, sp, kw = data.vocab_files("VG")
+            orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], data.merges_file("VG"))
+            d, o = synth.corpus(g["corpus"], g["n_docs"])
+            assert hashlib.sha256(d.tobytes()).hexdigest() == g["corpus_sha256"]
+            ids, oo, st = orc.encode_packed(d, o, 8)
+            res = [ids[oo[i]:oo[i + 1]].tolist() for i in range(g["n_docs"])]
+        else:
+            ents, sp = H.random_byte_vocab(g["seed"], n_merges=2000, proper=g["proper"], dup_ids=g["dup_ids"])
+            vp, spath = H.write_vocab(tmp_path, "g5_%d" % g["seed"], ents, sp)
+            mp = H.write_merges(tmp_path, "g5_%d" % g["seed"], H.random_merges_text(ents, g["seed"] * 3, keep=0.8))
+            orc = oracle_mod.Oracle(vp, spath, g["prefix"], True, mp)
+            rng = random.Random(g["seed"] * 1000)
+            res = orc.batch_encode([H.random_text(rng, max_words=30) for _ in range(1500)], 4)
+        assert res[:len(g["first"])] == g["first"]
+        assert sum(len(x) for x in res) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]

@@ -47,6 +47,18 @@ def test_initialize_errors(hutoken, tmp_path):
         hutoken.initialize("NYTK/PULI-LlumiX-32K")
 
 
+def test_merges_file_arguments(hutoken, tmp_path):
+    """hutoken.py:30-37: a merges file given positionally must exist (and is then dropped by the reference's
+    local-file branch); the keyword of the native initialize selects the id-keyed path here."""
+    ents, sp = H.random_byte_vocab(1, n_merges=20)
+    vp, spath = H.write_vocab(tmp_path, "v", ents, sp)
+    missing = str(tmp_path / "no_merges.txt")
+    with pytest.raises(ValueError, match="The provided merges file"):
+        hutoken.initialize(vp, spath, None, None, None, None, None, missing)  # args[6] of *args
+    with pytest.raises(ValueError, match="The provided merges file"):
+        hutoken.initialize(vp, spath, merges_file_path=missing)
+
+
 def test_out_of_path_features_fail_loudly(hutoken, tmp_path):
     ents, sp = H.random_byte_vocab(1, n_merges=20)
     vp, spath = H.write_vocab(tmp_path, "v", ents, sp)

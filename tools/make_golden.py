@@ -11,6 +11,10 @@ bit-for-bit) and the reference's outputs.  Run in the build container only.
   G3  VG (data/vg50257_*) x first 5000 docs of C2 and of C3   -> ids of the first 48 docs + count + sha256
   G4  VL (data/vl32000_*, prefix U+2581, is_byte_encoder=False) x first 3000 docs of C5 and
       2000 docs of C3 (unknown characters -> -1)              -> same
+  G5  the ID-KEYED merge path (a merges file): mid vocabularies with shuffled / duplicate ids and a
+      merges file whose rule order is unrelated to the ids (helpers.random_merges_text: comments,
+      skipped rules, repeated pairs, CRLF), with and without a prefix, x 1500 seeded texts; VG with
+      its merges file x 2000 docs of C3                       -> same
 """
 import hashlib
 import json
@@ -94,6 +98,27 @@ def g2(tmp):
     return out
 
 
+def g5(tmp):
+    out = []
+    for seed, proper, dup, prefix in [(21, False, False, None), (22, True, True, None), (23, True, False, "Ġ")]:
+        ents, sp = H.random_byte_vocab(seed, n_merges=2000, proper=proper, dup_ids=dup)
+        vp, spath = H.write_vocab(tmp, f"g5_{seed}", ents, sp)
+        mp = H.write_merges(tmp, f"g5_{seed}", H.random_merges_text(ents, seed * 3, keep=0.8))
+        r = ref.RefTokenizer(vp, spath, prefix, True, mp)
+        rng = random.Random(seed * 1000)
+        texts = [H.random_text(rng, max_words=30) for _ in range(1500)]
+        res = r.batch_encode(texts, 4)
+        out.append({"recipe": f"helpers.random_byte_vocab({seed}, n_merges=2000, proper={proper}, dup_ids={dup}); "
+                              f"merges: helpers.random_merges_text(entries, {seed * 3}, keep=0.8); prefix {prefix!r}; "
+                              f"texts: random.Random({seed * 1000}), helpers.random_text(rng, max_words=30) x 1500",
+                    "seed": seed, "proper": proper, "dup_ids": dup, "prefix": prefix,
+                    "first": res[:40], "n_ids": sum(len(x) for x in res), "sha256": sha_ids(res)})
+    vp, sp, kw = data.vocab_files("VG")
+    r = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"], data.merges_file("VG"))
+    out.append(dict(corpus_case(r, "C3", 2000), vocab="VG+merges"))
+    return out
+
+
 def corpus_case(tok, name, n_docs, nfirst=48):
     d, o = synth.corpus(name, n_docs)
     docs = synth.docs_as_str(d, o)
@@ -106,6 +131,9 @@ def main():
     assert ref.available(), "build the reference first: make -C oracle ref"
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
+    if "--only-g5" in sys.argv:
+        json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
+        return
     json.dump(g1(tmp), open(os.path.join(OUT, "g1_handpicked.json"), "w"), ensure_ascii=True, indent=0)
     json.dump(g2(tmp), open(os.path.join(OUT, "g2_mid_vocabs.json"), "w"))
     vp, sp, kw = data.vocab_files("VG")
@@ -117,6 +145,7 @@ def main():
     r = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"])
     g4 = [corpus_case(r, "C5", 3000), corpus_case(r, "C3", 2000)]
     json.dump(g4, open(os.path.join(OUT, "g4_vl_corpora.json"), "w"))
+    json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
