@@ -16,7 +16,8 @@ DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
 # every symbol include/hutoken_amd.h declares
 EXPORTS = [
     "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
-    "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size",
+    "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
+    "hutk_host_free",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
     "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
 ]
@@ -47,6 +48,10 @@ def load(build_if_missing=True):
     L.hutk_ctx_create_merges.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]
     L.hutk_uses_merges.restype = i32
     L.hutk_uses_merges.argtypes = [vp]
+    L.hutk_host_alloc.restype = vp
+    L.hutk_host_alloc.argtypes = [C.c_size_t]
+    L.hutk_host_free.restype = None
+    L.hutk_host_free.argtypes = [vp]
     L.hutk_ctx_destroy.restype = None
     L.hutk_ctx_destroy.argtypes = [vp]
     L.hutk_last_error.restype = C.c_char_p
@@ -94,6 +99,32 @@ _EXC = {E_FILE_NOT_FOUND: FileNotFoundError, E_VALUE: ValueError, E_MEMORY: Memo
 def raise_for(code):
     if code != OK:
         raise _EXC.get(code, RuntimeError)(last_error())
+
+
+class PinnedArray:
+    """A numpy array on page-locked host memory from hutk_host_alloc (kept alive by this object)."""
+
+    def __init__(self, n, dtype):
+        import numpy as np
+        self.dtype = np.dtype(dtype)
+        self.nbytes = max(int(n) * self.dtype.itemsize, 1)
+        self._p = load().hutk_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("hutk_host_alloc failed")
+        buf = (C.c_uint8 * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(n))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            load().hutk_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

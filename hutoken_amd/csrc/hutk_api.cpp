@@ -87,6 +87,16 @@ struct hutk_ctx {
     DevBuf<uint8_t> s_bytes;
     DevBuf<int64_t> s_offsets, s_out_offsets;
     DevBuf<int32_t> s_ids, s_status;
+    // pipelined host path (hutk_encode_batch on large batches): two sets of chunk buffers, copy streams,
+    // pinned staging for the rebased offsets and the small per-chunk results
+    struct Pipe {
+        DevBuf<uint8_t> bytes[2];
+        DevBuf<int64_t> offs[2], offs_abs[2], oo[2], base;  // base: ids of the chunks already encoded
+        DevBuf<int32_t> ids[2], status[2], err[2];
+        hipStream_t s_in = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        bool ready = false;
+    } pipe;
 
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -256,6 +266,16 @@ void destroy(hutk_ctx* c) {
         c->w_exc.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
+        for (int b = 0; b < 2; b++) {
+            c->pipe.bytes[b].release(); c->pipe.offs[b].release(); c->pipe.oo[b].release(); c->pipe.offs_abs[b].release();
+            c->pipe.ids[b].release(); c->pipe.status[b].release(); c->pipe.err[b].release();
+            if (c->pipe.ev_in[b]) (void)hipEventDestroy(c->pipe.ev_in[b]);
+            if (c->pipe.ev_comp[b]) (void)hipEventDestroy(c->pipe.ev_comp[b]);
+            if (c->pipe.ev_out[b]) (void)hipEventDestroy(c->pipe.ev_out[b]);
+        }
+        c->pipe.base.release();
+        if (c->pipe.s_in) (void)hipStreamDestroy(c->pipe.s_in);
+        if (c->pipe.s_out) (void)hipStreamDestroy(c->pipe.s_out);
         for (auto& e : c->ev)
             if (e) (void)hipEventDestroy(e);
         if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -538,8 +558,175 @@ int hutk_last_timing(hutk_ctx* c, float* ms_tile_kernel, float* ms_total) {
     return HUTK_OK;
 }
 
+static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                               int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status);
+static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
+                                  bool* redo_simple);
+
+// Batches of at least this many bytes go through the chunked path that overlaps the H2D copy of chunk c+1,
+// the kernels of chunk c and the D2H copy of chunk c-1 (worth it only when the copies dominate)
+static const int64_t PIPE_MIN_BYTES = 48ll << 20;
+static int64_t pipe_chunk_bytes(int64_t n_bytes) {  // an eighth of the batch, 16..64 MB; HUTK_PIPE_CHUNK_MB overrides
+    const char* e = getenv("HUTK_PIPE_CHUNK_MB");
+    if (e && atol(e) > 0) return (int64_t)atol(e) << 20;
+    const int64_t lo = 16ll << 20, hi = 64ll << 20;
+    return std::min(hi, std::max(lo, n_bytes / 8));
+}
+
 int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                       int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (c && !c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
+        offsets[n_docs] >= PIPE_MIN_BYTES && !getenv("HUTK_NO_PIPELINE")) {
+        bool redo = false;
+        const int rc = encode_batch_pipelined(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, &redo);
+        if (!redo) return rc;
+    }
+    return encode_batch_simple(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
+}
+
+void* hutk_host_alloc(size_t n_bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n_bytes ? n_bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void hutk_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+// Chunks of whole documents, double buffered.  Per chunk: bytes + offsets H2D on s_in; on the context's
+// stream the offsets are rebased, the kernel sequence runs and the chunk's out_offsets are made absolute with
+// a device-side running total; the out_offsets come back on s_out (their last entry places the ids in the
+// caller's array), then the ids.  No per-document work on the host.
+// *redo_simple: a document was cut at an over-long word -- rare, and handled by the simple path's trimming.
+static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
+                                  bool* redo_simple) {
+    *redo_simple = false;
+    for (int64_t i = 0; i < n_docs; i++)
+        if (offsets[i + 1] < offsets[i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
+    const int64_t n_bytes = offsets[n_docs];
+    if (!bytes || !ids_out) return set_err(HUTK_E_ARG, "bad argument");
+    if (ids_cap < hutk_ids_capacity(c, n_bytes, n_docs) - 1)
+        return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
+    HIP_TRY(hipSetDevice(c->device));
+    hutk_ctx::Pipe& P = c->pipe;
+    if (!P.ready) {
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipEventCreateWithFlags(&P.ev_in[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.ev_comp[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&P.ev_out[b], hipEventDisableTiming));
+        }
+        P.ready = true;
+    }
+    // chunk boundaries (whole documents)
+    const int64_t chunk_bytes = pipe_chunk_bytes(n_bytes);
+    std::vector<int64_t> first;  // first document of each chunk, plus n_docs
+    int64_t max_bytes = 0, max_docs = 0;
+    for (int64_t d = 0; d < n_docs;) {
+        first.push_back(d);
+        int64_t e = d + 1;
+        while (e < n_docs && offsets[e + 1] - offsets[d] <= chunk_bytes) e++;
+        max_bytes = std::max(max_bytes, offsets[e] - offsets[d]);
+        max_docs = std::max(max_docs, e - d);
+        d = e;
+    }
+    first.push_back(n_docs);
+    const int n_chunks = (int)first.size() - 1;
+    const int64_t max_ids = hutk_ids_capacity(c, max_bytes, max_docs);
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(P.bytes[b].reserve((size_t)max_bytes + 64));
+        HIP_TRY(P.offs[b].reserve((size_t)max_docs + 1));
+        HIP_TRY(P.offs_abs[b].reserve((size_t)max_docs + 1));
+        HIP_TRY(P.oo[b].reserve((size_t)max_docs + 1));
+        HIP_TRY(P.ids[b].reserve((size_t)max_ids + 1));
+        HIP_TRY(P.status[b].reserve((size_t)max_docs + 1));
+        HIP_TRY(P.err[b].reserve(1));
+    }
+    HIP_TRY(P.base.reserve(1));
+    {  // the workspace is grown once, for the largest chunk: growing it later would synchronise the device
+        Workspace W{};
+        const int rc = ensure_workspace(c, max_bytes, max_docs, (max_bytes + TILE_BYTES - 1) / TILE_BYTES, W);
+        if (rc) return rc;
+    }
+    hipStream_t sc = c->stream;
+    HIP_TRY(hipMemsetAsync(P.base.p, 0, 8, sc));
+    int64_t base = 0;  // ids of the chunks finalised so far
+    bool too_large = false;
+    int dev_err = 0;
+    auto finalize = [&](int ch) -> int {  // chunk ch: results to the caller's arrays
+        const int b = ch & 1;
+        const int64_t d0 = first[ch], nd = first[ch + 1] - d0;
+        HIP_TRY(hipStreamWaitEvent(P.s_out, P.ev_comp[b], 0));
+        int32_t err = 0;
+        HIP_TRY(hipMemcpyAsync(out_offsets + d0, P.oo[b].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, P.s_out));
+        HIP_TRY(hipMemcpyAsync(&err, P.err[b].p, 4, hipMemcpyDeviceToHost, P.s_out));
+        HIP_TRY(hipStreamSynchronize(P.s_out));
+        const int64_t total = out_offsets[d0 + nd] - base;  // the chunk's offsets are absolute already
+        if (err == HUTK_E_WORD_TOO_LARGE) too_large = true;
+        else if (err && !dev_err) dev_err = err;
+        if (base + total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
+        if (total)
+            HIP_TRY(hipMemcpyAsync(ids_out + base, P.ids[b].p, (size_t)total * 4, hipMemcpyDeviceToHost, P.s_out));
+        if (status && nd)
+            HIP_TRY(hipMemcpyAsync(status + d0, P.status[b].p, (size_t)nd * 4, hipMemcpyDeviceToHost, P.s_out));
+        HIP_TRY(hipEventRecord(P.ev_out[b], P.s_out));
+        base += total;
+        return HUTK_OK;
+    };
+    for (int ch = 0; ch < n_chunks; ch++) {
+        const int b = ch & 1;
+        const int64_t d0 = first[ch], nd = first[ch + 1] - d0;
+        const int64_t b0 = offsets[d0], nb = offsets[d0 + nd] - b0;
+        if (ch >= 2) HIP_TRY(hipEventSynchronize(P.ev_out[b]));  // buffers b are free again
+        if (nb) HIP_TRY(hipMemcpyAsync(P.bytes[b].p, bytes + b0, (size_t)nb, hipMemcpyHostToDevice, P.s_in));
+        HIP_TRY(hipMemcpyAsync(P.offs_abs[b].p, offsets + d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, P.s_in));
+        HIP_TRY(hipEventRecord(P.ev_in[b], P.s_in));
+        HIP_TRY(hipStreamWaitEvent(sc, P.ev_in[b], 0));
+        launch_rebase_offsets(P.offs_abs[b].p, P.offs[b].p, nd + 1, sc);  // relative to the chunk's first byte
+        const int rc = hutk_encode_batch_device(c, P.bytes[b].p, P.offs[b].p, nd, nb, P.ids[b].p, max_ids, P.oo[b].p,
+                                                P.status[b].p, P.err[b].p, sc);
+        if (rc) {
+            (void)hipDeviceSynchronize();
+            return rc;
+        }
+        launch_add_base(P.oo[b].p, nd + 1, P.base.p, sc);  // out_offsets absolute; base moves on
+        HIP_TRY(hipEventRecord(P.ev_comp[b], sc));
+        if (ch >= 1) {
+            const int frc = finalize(ch - 1);
+            if (frc) {
+                (void)hipDeviceSynchronize();
+                return frc;
+            }
+        }
+    }
+    {
+        const int frc = finalize(n_chunks - 1);
+        if (frc) {
+            (void)hipDeviceSynchronize();
+            return frc;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(P.s_out));
+    out_offsets[n_docs] = base;
+    if (too_large && !dev_err) {
+        *redo_simple = true;  // the simple path trims the cut documents
+        return HUTK_OK;
+    }
+    switch (dev_err) {
+        case HUTK_OK: return HUTK_OK;
+        case HUTK_E_NUL_BYTE: return set_err(dev_err, "a document contains a 0x00 byte");
+        case HUTK_E_INVALID_UTF8: return set_err(dev_err, "text is not valid UTF-8 (non-byte-encoder mode)");
+        case HUTK_E_CAPACITY: return set_err(dev_err, "ids_cap too small");
+        default: return set_err(dev_err, "device-side failure");
+    }
+}
+
+static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                               int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
     if (n_docs < 0 || !offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");

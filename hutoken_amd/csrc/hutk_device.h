@@ -106,6 +106,8 @@ struct BatchArgs {
 
 // hutk_kernels.hip
 void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s);
+void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s);  // v[i] += *base; *base = v[n-1]
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);

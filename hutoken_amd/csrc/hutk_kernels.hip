@@ -1495,6 +1495,26 @@ void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, h
     else hipLaunchKernelGGL(k_gather<uint32_t>, g, b, 0, s, t, a, w);
     hipLaunchKernelGGL(k_gather_exc, dim3(1024), dim3(GATHER_THREADS), 0, s, t, a, w);
 }
+// chunked host path (hutk_api.cpp): document offsets of a chunk made relative to its first byte, and the
+// chunk's out_offsets made absolute by the ids of the chunks before it (a device scalar)
+__global__ void k_rebase_offsets(const int64_t* in, int64_t* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] - in[0];
+}
+__global__ void k_add_base(int64_t* v, int64_t n, const int64_t* base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += *base;
+}
+__global__ void k_copy_one(int64_t* dst, const int64_t* src) { *dst = *src; }
+
+void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+}
+void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_base, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, base);
+    hipLaunchKernelGGL(k_copy_one, dim3(1), dim3(1), 0, s, base, v + (n - 1));
+}
+
 void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const unsigned g = (unsigned)((a.n_docs + 1 + 255) / 256);
     hipLaunchKernelGGL(k_doc_off, dim3(g), dim3(256), 0, s, a, w);

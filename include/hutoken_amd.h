@@ -112,6 +112,13 @@ int hutk_encode_batch_device(hutk_ctx* ctx, const uint8_t* d_bytes, const int64_
                              int64_t ids_cap, int64_t* d_out_offsets, int32_t* d_status,
                              int32_t* d_err, void* hip_stream);
 
+/* Page-locked host memory for the buffers handed to hutk_encode_batch: with it the chunked
+ * path of hutk_encode_batch copies by DMA while the previous chunk is being encoded and the one
+ * before is being copied back (pageable buffers work too, at roughly a third of the rate).
+ * The reference has no counterpart (it strdup()s every text, src/lib.c:770-772). */
+void* hutk_host_alloc(size_t n_bytes);
+void hutk_host_free(void* p);
+
 /* Replaces p_encode, src/lib.c:668-720 (one document on the calling thread). */
 int hutk_encode(hutk_ctx* ctx, const uint8_t* text, int64_t len, int32_t* ids_out,
                 int64_t ids_cap, int64_t* n_ids, int32_t* status);

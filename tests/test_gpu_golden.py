@@ -197,3 +197,44 @@ def test_g5_merges_path(tmp_path):
         assert res[:len(g["first"])] == g["first"]
         assert sum(len(x) for x in res) == g["n_ids"]
         assert sha_ids(res) == g["sha256"]
+
+
+def test_chunked_host_path_equals_the_simple_one(vg_files, monkeypatch):
+    """hutk_encode_batch on a large batch overlaps copies and kernels chunk by chunk (pageable and page-locked
+    buffers); same ids, offsets and status as the unchunked path, including a document cut at an over-long
+    word, which sends the whole batch through the simple path's trimming."""
+    from hutoken_amd import _capi, synth
+    vp, sp, kw = vg_files
+    ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C3", 150000)  # 76 MB: above the 48 MB threshold, five chunks
+    monkeypatch.setenv("HUTK_NO_PIPELINE", "1")
+    ids_s, oo_s, st_s, rc = ctx.encode_packed(d, o)
+    assert rc == 0
+    monkeypatch.delenv("HUTK_NO_PIPELINE")
+    ids_c, oo_c, st_c, rc = ctx.encode_packed(d, o)
+    assert rc == 0
+    assert np.array_equal(oo_s, oo_c) and np.array_equal(ids_s, ids_c) and np.array_equal(st_s, st_c)
+    # page-locked buffers through the raw C ABI
+    n = len(o) - 1
+    cap = ctx.ids_capacity(len(d), n)
+    pb, po = _capi.PinnedArray(len(d), np.uint8), _capi.PinnedArray(n + 1, np.int64)
+    pi, poo, pst = _capi.PinnedArray(cap, np.int32), _capi.PinnedArray(n + 1, np.int64), _capi.PinnedArray(n, np.int32)
+    pb.array[:] = d
+    po.array[:] = o
+    rc = _capi.load().hutk_encode_batch(ctx.handle, pb.array.ctypes.data, po.array.ctypes.data, n, pi.array.ctypes.data,
+                                        cap, poo.array.ctypes.data, pst.array.ctypes.data)
+    assert rc == 0
+    assert np.array_equal(poo.array, oo_s) and np.array_equal(pi.array[: int(oo_s[-1])], ids_s)
+    # an over-long word in the middle of a chunked batch
+    docs_mid = int(n // 2)
+    cut_at = int(o[docs_mid])
+    big = np.frombuffer(b"x" * 262200 + b" tail", dtype=np.uint8)
+    d2 = np.concatenate([d[:cut_at], big, d[cut_at:]])
+    o2 = np.concatenate([o[: docs_mid + 1], o[docs_mid:] + len(big)]).astype(np.int64)
+    o2[docs_mid + 1] = cut_at + len(big)
+    ids_c2, oo_c2, st_c2, rc = ctx.encode_packed(d2, o2)
+    monkeypatch.setenv("HUTK_NO_PIPELINE", "1")
+    ids_s2, oo_s2, st_s2, rc2 = ctx.encode_packed(d2, o2)
+    assert rc == 0 and rc2 == 0
+    assert st_c2[docs_mid] == 1 and oo_c2[docs_mid + 1] == oo_c2[docs_mid]
+    assert np.array_equal(oo_s2, oo_c2) and np.array_equal(ids_s2, ids_c2) and np.array_equal(st_s2, st_c2)
