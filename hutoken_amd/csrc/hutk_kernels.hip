@@ -4,38 +4,39 @@
 // Pipeline of one batch (all on one stream, no host round trip):
 //
 //   k_pre      per tile: first document that can touch the tile (binary search)
-//   k_tiles    THE hot kernel.  ONE WAVEFRONT owns 960 input bytes (no workgroup barrier
-//              ever waits on another wavefront's long word):
-//                1. coalesced 16-byte loads of the bytes (+16 before, +80 after) into LDS
-//                2. document-start bitmap of the window
-//                3. each lane classifies its 16 positions IN REGISTERS from a 32-byte
+//   k_tiles    THE hot kernel.  One wavefront per tile of 960 input bytes, TILE_WAVES tiles per
+//              workgroup in byte-encoder mode (1 otherwise):
+//                1. coalesced 16-byte loads of the bytes (+16 before, +80 after) into LDS,
+//                   document-start bitmap of the window
+//                2. each lane classifies its 16 positions IN REGISTERS from a 32-byte
 //                   window (the reference's splitter, src/parser.c:24-183, is a function
 //                   of a +-5 byte neighbourhood) and emits 16 word-start bits
-//                4. byte-encoder mode: symbols (byte -> symbol LUT) and the rank of every
-//                   adjacent byte pair straight from a 65536-entry table, 16 independent
-//                   loads per lane
-//                5. words bucketed by unit count, longest first
-//                6. PERSISTENT LANES, ONE WORD PER LANE: each lane pulls the next word
-//                   from an LDS cursor and all lanes take one step of the reference's
-//                   merge rule "leftmost pair of minimal rank" per trip (src/core.c:66-209,
-//                   src/queue.c:152-199); symbols and pair results live in LDS, the two
-//                   new neighbour pairs are looked up together in the device pair table
-//                7. wave scan (__shfl_up) of per-word id counts, dense id run written out
-//                8. ids-before-document-start for every document that starts in the tile
+//                3. words go to the lanes round-robin; one round = one memory round trip:
+//                   whole-word table probe (raw bytes -> the single token of the word),
+//                   first-byte symbol, unit count; outcome: one symbol / needs merging /
+//                   exception
+//                4. the merge-loop words of the workgroup's tiles are pooled (long ones
+//                   first) and taken 64 at a time, ONE WORD PER LANE, one merge per trip:
+//                   the reference's rule "leftmost pair of minimal rank" (src/core.c:66-209,
+//                   src/queue.c:152-199); symbols and pair results in LDS, the two new
+//                   neighbour pairs looked up together in the cuckoo pair table
+//                5. epilogue on bitmaps of surviving units and exception words: popcounts,
+//                   DPP wave scan, symbols stored to the tile's run, ids-before-document-
+//                   start for every document that starts in the tile
 //              Words a lane cannot take (more than 32 units or 63 bytes, end outside the
-//              staged window, or first word of a document when a prefix is configured)
-//              become exception records.
-//   k_exc      one wavefront per exception word, work pulled from a device counter:
-//              the same merge rule, cooperatively (parallel min over the pair array,
-//              __shfl_xor reduction), arrays in LDS up to 1024 units, else in HBM.
+//              staged window, beyond the tile's prefix budget) become exception records.
+//   k_exc      one wavefront per exception word, work pulled from a device counter: the same
+//              merge rule by the whole wavefront; up to 1024 units in LDS (dense arrays), beyond
+//              that in HBM with dead-unit marks and per-chunk minima (bpe_wave_big).
 //   k_scan_*   exclusive scan of per-tile id counts (block sums, scan of sums, apply)
-//   k_gather   tile runs (+ exception words) -> caller's ids array
+//   k_gather   tile runs -> caller's ids array (symbol -> id); k_gather_exc for the tiles that
+//              also hold exception words
 //   k_doc_off  out_offsets[]
 //
-// Rank of a pair = vocabulary id of the concatenated bytes (src/core.c:700-722).
-// On the device every possible token is a 20-bit symbol numbered in id order, and
-// (left, right) -> merged is one 8-byte slot of an open-addressing table built by
-// hutk_loader.cpp; with unique ids "smaller merged symbol" == "smaller rank".
+// Rank of a pair = vocabulary id of the concatenated bytes (src/core.c:700-722), or the rule's
+// line order on the id-keyed path (src/core.c:211-337).  On the device every possible token is a
+// 20-bit symbol numbered so that "smaller merged symbol" == "smaller rank", and
+// (left, right) -> merged is one 8-byte slot of a two-choice cuckoo table built by hutk_loader.cpp.
 #include <hip/hip_runtime.h>
 
 #include "hutk_classify.h"
