@@ -81,6 +81,7 @@ struct hutk_ctx {
     DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
+    DevBuf<uint32_t> w_exc_long;
     DevBuf<int32_t> w_err;
 
     // staging for the host-buffer entry point
@@ -226,6 +227,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_err.reserve(1));
     const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
+    HIP_TRY(c->w_exc_long.reserve((size_t)cap_exc));
     W.run = c->w_run.p;
     W.exc_tok = c->w_exc_tok.p;
     W.exc_sym = c->w_exc_sym.p;
@@ -242,6 +244,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.scan_part = c->w_tile_i64.p + 2 * n_tiles + 2;
     W.doc_tile_pos = c->w_doc_pos.p;
     W.exc = c->w_exc.p;
+    W.exc_long = c->w_exc_long.p;
     W.counters = c->w_counters.p;
     W.cap_exc = cap_exc;
     W.pad_per_doc = (int32_t)pad;
@@ -263,7 +266,7 @@ void destroy(hutk_ctx* c) {
         c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
-        c->w_exc.release(); c->w_err.release();
+        c->w_exc.release(); c->w_exc_long.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
         for (int b = 0; b < 2; b++) {

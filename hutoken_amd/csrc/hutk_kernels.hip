@@ -1082,6 +1082,170 @@ __device__ int64_t bpe_wave_big(const DevTables& T, HbmArr Sg, HbmArr Mg, uint32
 }
 
 
+// document holding byte ws of tile `tile`: last d with offsets[d] <= ws.  The tile metadata brackets it
+// (tile_first_doc = first document at or after the tile start - LOOKBACK), so the search is two or three
+// probes instead of log2(n_docs).
+__device__ __forceinline__ int64_t doc_of(const BatchArgs& A, const Workspace& W, int64_t ws, uint32_t tile) {
+    const int64_t f = W.tile_first_doc[tile];
+    int64_t lo = f > 0 ? f - 1 : 0;                                                     // offsets[lo] <= ws
+    int64_t hi = ((int64_t)tile + 2 < A.n_tiles) ? W.tile_first_doc[tile + 2] : A.n_docs;  // offsets[hi] > ws
+    if (hi > A.n_docs) hi = A.n_docs;
+    if (hi <= lo) hi = lo + 1;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (A.offsets[mid] <= ws) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------
+// k_exc_medium: exception words whose end the tile could see (at most 63 bytes, so at most 63 units) and
+// that were refused only for having more than 32 units (or, non-byte mode, for the prefix budget): ONE LANE
+// PER WORD, 64 words per wavefront, the merge loop of k_tiles with 64-bit unit masks.  Whatever it does not
+// take (unknown end, more than 64 units with a prefix) is left for k_exc, one wavefront per word.
+// ------------------------------------------------------------------------
+constexpr int MEDIUM_UNITS = 64;
+template <typename SymT>
+__global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Workspace W) {
+    // 16-bit symbols when the vocabulary allows: half the LDS, twice the resident wavefronts (the loop is
+    // bound by the latency of its pair lookups)
+    __shared__ SymT Sm[MEDIUM_UNITS * 64];  // unit i of the lane's word at [i * 64 + lane]
+    __shared__ SymT Mm[MEDIUM_UNITS * 64];  // merged symbol of (unit i, next live unit) or NONE
+    const int lane = threadIdx.x;
+    const uint32_t n_exc = W.counters[0];
+    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n_exc && (int64_t)base < W.cap_exc;
+         base += (uint64_t)gridDim.x * 64) {
+        const uint64_t idx = base + lane;
+        bool have = idx < n_exc && (int64_t)idx < W.cap_exc;
+        ExcRec rec{};
+        if (have) rec = W.exc[idx];
+        have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
+        int64_t d = 0, gbase = 0;
+        int n = 0, na = 0;
+        uint64_t live = 0, cand = 0;
+        if (have) {
+            const int64_t ws = rec.ws;
+            const int nb = rec.len;
+            d = doc_of(A, W, ws, rec.tile);
+            const bool docfirst = ws == A.offsets[d];
+            const bool with_prefix = T.has_prefix && docfirst;
+            const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
+            const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
+            na = alone ? T.n_prefix_alone : 0;
+            gbase = ws + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            if (kp + nb > MEDIUM_UNITS) {
+                have = false;  // k_exc
+            } else {
+                for (int i = 0; i < kp; i++) Sm[i * 64 + lane] = Sym<SymT>::narrow(T.prefix_syms[i]);
+                n = kp;
+                if (T.is_byte_encoder) {
+                    for (int i = 0; i < nb; i++) Sm[(n + i) * 64 + lane] = Sym<SymT>::narrow(T.item_sym[A.bytes[ws + i]]);
+                    n += nb;
+                } else {
+                    for (int i = 0; i < nb;) {
+                        const uint32_t b = A.bytes[ws + i];
+                        int L = (b < 0x80u) ? 1 : (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                        uint32_t sym;
+                        if ((b >= 0x80u && (L == 1 || b >= 0xF8u)) || i + L > nb) {
+                            raise(A.err, HUTK_E_INVALID_UTF8);
+                            sym = SYM_UNK;
+                            L = 1;
+                        } else if (T.item_direct[b]) {
+                            sym = T.item_sym[b];
+                        } else if (L == 1) {
+                            sym = SYM_UNK;
+                        } else {
+                            uint32_t packed = b | ((uint32_t)A.bytes[ws + i + 1] << 8);
+                            if (L > 2) packed |= (uint32_t)A.bytes[ws + i + 2] << 16;
+                            if (L > 3) packed |= (uint32_t)A.bytes[ws + i + 3] << 24;
+                            sym = char_lookup(T, packed);
+                        }
+                        Sm[n * 64 + lane] = Sym<SymT>::narrow(sym);
+                        n++;
+                        i += L;
+                    }
+                }
+                live = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+                for (int i0 = 0; i0 + 1 < n; i0 += 4) {  // four lookups (eight loads) in flight
+                    PairProbe pr[4];
+                    uint32_t sy[5];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) sy[j] = (i0 + j < n) ? Sym<SymT>::widen(Sm[(i0 + j) * 64 + lane]) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i0 + j + 1 < n) {
+                            const uint32_t m = pair_resolve(pr[j], sy[j], sy[j + 1]);
+                            Mm[(i0 + j) * 64 + lane] = Sym<SymT>::narrow(m);
+                            if (m != SYM_NONE) cand |= 1ull << (i0 + j);
+                        }
+                }
+            }
+        }
+        // one merge per trip and lane: the candidate of minimal rank, leftmost on ties (queue.c:162-164)
+        for (;;) {
+            const bool act = have && cand != 0;
+            if (!__any(act)) break;
+            if (act) {
+                uint32_t br = 0xFFFFFFFFu, bm = 0;
+                int bp = 0;
+                for (uint64_t c = cand; c; c &= c - 1) {
+                    const int i = __builtin_ctzll(c);
+                    const uint32_t m = Sym<SymT>::widen(Mm[i * 64 + lane]);
+                    const uint32_t r = rank_of(T, m);
+                    if (r < br) {
+                        br = r;
+                        bp = i;
+                        bm = m;
+                    }
+                }
+                const int p = bp;
+                const uint64_t above = live & ~((2ull << p) - 1ull);
+                const int q = __builtin_ctzll(above);  // the unit the merge consumes
+                Sm[p * 64 + lane] = Sym<SymT>::narrow(bm);
+                live &= ~(1ull << q);
+                cand &= ~((1ull << q) | (1ull << p));
+                const uint64_t right = above & (above - 1ull);
+                const uint64_t left = live & ((1ull << p) - 1ull);
+                const int p0 = left ? 63 - __builtin_clzll(left) : 0;
+                const uint32_t sr = right ? Sym<SymT>::widen(Sm[__builtin_ctzll(right) * 64 + lane]) : 0u;
+                const uint32_t sl = left ? Sym<SymT>::widen(Sm[p0 * 64 + lane]) : 0u;
+                const PairProbe pr = pair_issue(T, bm, sr), pl = pair_issue(T, sl, bm);  // both in flight
+                if (right) {
+                    const uint32_t m = pair_resolve(pr, bm, sr);
+                    Mm[p * 64 + lane] = Sym<SymT>::narrow(m);
+                    if (m != SYM_NONE) cand |= 1ull << p;
+                }
+                if (left) {
+                    const uint32_t m = pair_resolve(pl, sl, bm);
+                    Mm[p0 * 64 + lane] = Sym<SymT>::narrow(m);
+                    if (m != SYM_NONE) cand |= 1ull << p0; else cand &= ~(1ull << p0);
+                }
+            }
+        }
+        if (have) {
+            int32_t* out = W.exc_tok + gbase;
+            for (int i = 0; i < na; i++) out[i] = T.prefix_alone_ids[i];
+            int k = na;
+            for (uint64_t c = live; c; c &= c - 1) out[k++] = sym_to_id(T, Sym<SymT>::widen(Sm[__builtin_ctzll(c) * 64 + lane]));
+            rec.cnt = (uint32_t)k;
+            rec.tok_base = gbase;
+            W.exc[idx] = rec;
+            atomicAdd(&W.tile_count[rec.tile], rec.cnt);
+        }
+        // what is left goes on k_exc's list: one atomic per wavefront, not one per record
+        const bool leave = !have && idx < n_exc && (int64_t)idx < W.cap_exc;
+        const unsigned long long lb = __ballot(leave);
+        if (lb) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&W.counters[3], (uint32_t)__popcll(lb));
+            at = __shfl(at, 0, 64);
+            if (leave) W.exc_long[at + __popcll(lb & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t Sl[EXC_LDS_UNITS];
     __shared__ uint32_t Ml[EXC_LDS_UNITS];
@@ -1091,28 +1255,22 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
     __shared__ uint32_t s_idx;
 
     const int lane = threadIdx.x;
-    const uint32_t n_exc = W.counters[0];
+    const uint32_t n_list = W.counters[3];  // the records k_exc_medium did not take
     // first record by block index, further ones from the device cursor: no atomic
     // traffic at all when there are fewer records than wavefronts
     for (uint32_t round = 0;; round++) {
-        uint32_t idx = blockIdx.x;
+        uint32_t li = blockIdx.x;
         if (round) {
             if (lane == 0) s_idx = gridDim.x + atomicAdd(&W.counters[1], 1u);
             __syncthreads();
-            idx = s_idx;
+            li = s_idx;
             __syncthreads();
         }
-        if (idx >= n_exc || (int64_t)idx >= W.cap_exc) break;
+        if (li >= n_list) break;
+        const uint32_t idx = W.exc_long[li];
         ExcRec rec = W.exc[idx];
         const int64_t ws = rec.ws;
-
-        // document holding ws: last d with offsets[d] <= ws
-        int64_t lo = 0, hi = A.n_docs;  // invariant: offsets[lo] <= ws, answer in [lo, hi)
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (A.offsets[mid] <= ws) lo = mid; else hi = mid;
-        }
-        const int64_t d = lo, ds = A.offsets[d], de = A.offsets[d + 1];
+        const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
 
         // word end, when the tile could not see it
         int64_t we = ws + rec.len;
@@ -1481,6 +1639,9 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     // fixed grid; every wavefront pulls records until the device counter runs out
+    // words of at most 63 bytes, 64 per wavefront
+    if (t.sym16) hipLaunchKernelGGL(k_exc_medium<uint16_t>, dim3(2560), dim3(64), 0, s, t, a, w);
+    else hipLaunchKernelGGL(k_exc_medium<uint32_t>, dim3(1280), dim3(64), 0, s, t, a, w);
     hipLaunchKernelGGL(k_exc, dim3(4096), dim3(64), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
