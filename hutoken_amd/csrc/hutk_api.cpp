@@ -81,7 +81,7 @@ struct hutk_ctx {
     DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
-    DevBuf<uint32_t> w_exc_long;
+    DevBuf<uint32_t> w_exc_long, w_exc_quad, w_exc_wave;
     DevBuf<int32_t> w_err;
 
     // staging for the host-buffer entry point
@@ -223,11 +223,13 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 6 + 8));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
-    HIP_TRY(c->w_counters.reserve(4));
+    HIP_TRY(c->w_counters.reserve(8));
     HIP_TRY(c->w_err.reserve(1));
     const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_long.reserve((size_t)cap_exc));
+    HIP_TRY(c->w_exc_quad.reserve((size_t)cap_exc));
+    HIP_TRY(c->w_exc_wave.reserve((size_t)cap_exc));
     W.run = c->w_run.p;
     W.exc_tok = c->w_exc_tok.p;
     W.exc_sym = c->w_exc_sym.p;
@@ -245,6 +247,8 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.doc_tile_pos = c->w_doc_pos.p;
     W.exc = c->w_exc.p;
     W.exc_long = c->w_exc_long.p;
+    W.exc_quad = c->w_exc_quad.p;
+    W.exc_wave = c->w_exc_wave.p;
     W.counters = c->w_counters.p;
     W.cap_exc = cap_exc;
     W.pad_per_doc = (int32_t)pad;
@@ -266,7 +270,7 @@ void destroy(hutk_ctx* c) {
         c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
-        c->w_exc.release(); c->w_exc_long.release(); c->w_err.release();
+        c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
         for (int b = 0; b < 2; b++) {
@@ -522,7 +526,7 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
     c->ev_valid = false;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
     HIP_TRY(hipMemsetAsync(A.err, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(W.counters, 0, 16, s));
+    HIP_TRY(hipMemsetAsync(W.counters, 0, 32, s));
     if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
     if (n_tiles == 0) {
         HIP_TRY(hipMemsetAsync(d_out_offsets, 0, (size_t)(n_docs + 1) * 8, s));

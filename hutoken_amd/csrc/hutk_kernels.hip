@@ -1246,6 +1246,198 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
     }
 }
 
+// ------------------------------------------------------------------------
+// k_exc_quad: words of 64..256 units (byte-encoder mode, rank == symbol order): SIXTEEN LANES PER WORD, four
+// words per wavefront.  Lane l of a group owns units 16l..16l+15: it keeps the best (rank, position) key of
+// its own pairs in a register, the group minimum is a DPP row reduction, a consumed unit is marked dead
+// (no compaction), and only the lanes whose pairs changed rescan.  A merge costs one round trip of pair
+// lookups for four words at once instead of ~2 us for one word in k_exc.
+// ------------------------------------------------------------------------
+constexpr int QUAD_UNITS = 256;
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {  // minimum over each row of 16 lanes, in every lane
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    return (uint32_t)__shfl((int)v, (int)(threadIdx.x | 15), 64);  // lane 15 of the row holds it
+}
+__device__ __forceinline__ uint32_t row_excl_sum(uint32_t v) {  // exclusive prefix sum inside each row of 16 lanes
+    uint32_t inc = v;
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+    return inc - v;
+}
+
+__global__ __launch_bounds__(64) void k_exc_quad(DevTables T, BatchArgs A, Workspace W) {
+    __shared__ uint32_t Sq[4 * QUAD_UNITS];
+    __shared__ uint32_t Mq[4 * QUAD_UNITS];
+    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, gl0 = lane & 48;  // group, lane in group, its lane 0
+    uint32_t* Sg = Sq + g * QUAD_UNITS;
+    uint32_t* Mg = Mq + g * QUAD_UNITS;
+    const uint32_t n_list = W.counters[4];
+    for (uint32_t base = blockIdx.x * 4; base < n_list; base += gridDim.x * 4) {
+        const uint32_t li = base + g;
+        bool have = li < n_list;
+        uint32_t idx = 0;
+        ExcRec rec{};
+        if (have) {
+            idx = W.exc_quad[li];
+            rec = W.exc[idx];
+        }
+        int n = 0, na = 0;
+        int64_t gbase = 0;
+        if (have) {
+            const int64_t ws = rec.ws;
+            const int64_t d = doc_of(A, W, ws, rec.tile);
+            const bool docfirst = ws == A.offsets[d];
+            const bool with_prefix = T.has_prefix && docfirst;
+            const bool alone = with_prefix && A.bytes[ws] == ' ';
+            const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
+            na = alone ? T.n_prefix_alone : 0;
+            gbase = ws + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            {
+                n = kp + rec.len;  // <= QUAD_UNITS: the ends pass checked
+                for (int i = l; i < kp; i += 16) Sg[i] = T.prefix_syms[i];
+                for (int i = l; i < rec.len; i += 16) Sg[kp + i] = T.item_sym[A.bytes[ws + i]];
+            }
+        }
+        wave_sync();
+        // my 16 units: pair results and liveness
+        const int lo = 16 * l;
+        uint32_t live16 = 0;
+        if (have) {
+            const int cnt = n - lo;
+            live16 = cnt >= 16 ? 0xFFFFu : cnt > 0 ? ((1u << cnt) - 1u) : 0u;
+        }
+        for (int k0 = 0; k0 < 16; k0 += 4) {  // four lookups in flight
+            PairProbe pr[4];
+            uint32_t sy[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) sy[j] = (have && lo + k0 + j < n) ? Sg[lo + k0 + j] : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (have && lo + k0 + j < n)
+                    Mg[lo + k0 + j] = (lo + k0 + j + 1 < n) ? pair_resolve(pr[j], sy[j], sy[j + 1]) : SYM_NONE;
+        }
+        wave_sync();
+        bool dirty = true;
+        uint32_t mybest = 0xFFFFFFFFu;  // (merged symbol = rank) << 8 | unit index, over my live units
+        for (;;) {
+            if (dirty) {
+                mybest = 0xFFFFFFFFu;
+                for (uint32_t c = live16; c; c &= c - 1) {
+                    const int i = lo + __builtin_ctz(c);
+                    const uint32_t m = Mg[i];
+                    if (m != SYM_NONE) mybest = min(mybest, (m << 8) | (uint32_t)i);
+                }
+                dirty = false;
+            }
+            const uint32_t gbest = row_min_u32(have ? mybest : 0xFFFFFFFFu);
+            const bool act = gbest != 0xFFFFFFFFu;
+            if (!__any(act)) break;
+            // neighbours of the pair, from the per-lane liveness masks of the group (all shuffles unconditional)
+            const int p = (int)(gbest & 0xFFu);
+            const uint32_t ne = (uint32_t)(__ballot(live16 != 0) >> gl0) & 0xFFFFu;  // lanes of my group with live units
+            auto live_of = [&](int x) -> uint32_t { return (uint32_t)__shfl((int)live16, gl0 | (x & 15), 64); };
+            auto next_after = [&](int pos) -> int {
+                const int lx = pos >> 4;
+                const uint32_t a = live_of(lx) & ~((2u << (pos & 15)) - 1u) & 0xFFFFu;
+                const uint32_t m = ne & ~((2u << lx) - 1u) & 0xFFFFu;
+                const int ly = m ? __builtin_ctz(m) : 0;
+                const uint32_t lv = live_of(ly);
+                return a ? (pos & ~15) + __builtin_ctz(a) : (m && lv) ? 16 * ly + __builtin_ctz(lv) : -1;
+            };
+            auto prev_before = [&](int pos) -> int {
+                const int lx = pos >> 4;
+                const uint32_t a = live_of(lx) & ((1u << (pos & 15)) - 1u);
+                const uint32_t m = ne & ((1u << lx) - 1u);
+                const int ly = m ? 31 - __builtin_clz(m) : 0;
+                const uint32_t lv = live_of(ly);
+                return a ? (pos & ~15) + (31 - __builtin_clz(a)) : (m && lv) ? 16 * ly + (31 - __builtin_clz(lv)) : -1;
+            };
+            const int q = next_after(act ? p : 0);           // the unit the merge consumes
+            const int q2 = next_after(q >= 0 ? q : 0);
+            const int p0 = prev_before(act ? p : 0);
+            const uint32_t merged = gbest >> 8;
+            const uint32_t sr = (act && q >= 0 && q2 >= 0) ? Sg[q2] : 0u;
+            const uint32_t sl = (act && p0 >= 0) ? Sg[p0] : 0u;
+            const PairProbe prr = pair_issue(T, merged, sr), prl = pair_issue(T, sl, merged);
+            const uint32_t mr = (act && q >= 0 && q2 >= 0) ? pair_resolve(prr, merged, sr) : SYM_NONE;
+            const uint32_t ml = (act && p0 >= 0) ? pair_resolve(prl, sl, merged) : SYM_NONE;
+            wave_sync();  // everybody has read S before the owners write
+            if (act && q >= 0) {
+                if (l == (p >> 4)) {
+                    Sg[p] = merged;
+                    Mg[p] = mr;
+                    dirty = true;
+                }
+                if (l == (q >> 4)) {
+                    live16 &= ~(1u << (q & 15));
+                    Mg[q] = SYM_NONE;
+                    dirty = true;
+                }
+                if (p0 >= 0 && l == (p0 >> 4)) {
+                    Mg[p0] = ml;
+                    dirty = true;
+                }
+            }
+            wave_sync();
+        }
+        // survivors in order: alone ids, then each lane's live units at its row prefix
+        const uint32_t mine = (uint32_t)__popc(live16);
+        const uint32_t before = row_excl_sum(have ? mine : 0u);
+        const uint32_t total = (uint32_t)__shfl((int)(before + (have ? mine : 0u)), lane | 15, 64);
+        if (have) {
+            int32_t* out = W.exc_tok + gbase;
+            for (int i = l; i < na; i += 16) out[i] = T.prefix_alone_ids[i];
+            uint32_t k = (uint32_t)na + before;
+            for (uint32_t c = live16; c; c &= c - 1) out[k++] = sym_to_id(T, Sg[lo + __builtin_ctz(c)]);
+            if (l == 0) {
+                rec.cnt = (uint32_t)na + total;
+                rec.tok_base = gbase;
+                W.exc[idx] = rec;
+                atomicAdd(&W.tile_count[rec.tile], rec.cnt);
+            }
+        }
+        wave_sync();
+    }
+}
+
+// After the ends pass: the list k_exc_medium left is split into k_exc_quad's and k_exc's lists, 64 entries per
+// wavefront and one atomic per wavefront and list (one per record would serialise on the counter).
+__global__ __launch_bounds__(64) void k_exc_split(Workspace W) {
+    const int lane = threadIdx.x;
+    const uint32_t n_list = W.counters[3];
+    for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
+        const uint32_t li = base + lane;
+        uint32_t idx = 0;
+        int64_t cls = 0;
+        if (li < n_list) {
+            idx = W.exc_long[li];
+            const ExcRec r = W.exc[idx];
+            cls = (r.tok_base < 0) ? 0 : r.out_pos;  // cut documents (over-long word) are on no list
+        }
+        const unsigned long long bq = __ballot(cls == 1), bw = __ballot(cls == 2);
+        uint32_t aq = 0, aw = 0;
+        if (lane == 0) {
+            if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
+            if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
+        }
+        aq = __shfl(aq, 0, 64);
+        aw = __shfl(aw, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (cls == 1) W.exc_quad[aq + __popcll(bq & below)] = idx;
+        if (cls == 2) W.exc_wave[aw + __popcll(bw & below)] = idx;
+    }
+}
+
+// ENDS_ONLY: first pass over the list -- find the end of every word whose end the tile could not see and
+// store its length (k_exc_quad needs it); the regular pass then skips what k_exc_quad has encoded.
+template <bool ENDS_ONLY>
 __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t Sl[EXC_LDS_UNITS];
     __shared__ uint32_t Ml[EXC_LDS_UNITS];
@@ -1255,19 +1447,21 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
     __shared__ uint32_t s_idx;
 
     const int lane = threadIdx.x;
-    const uint32_t n_list = W.counters[3];  // the records k_exc_medium did not take
-    // first record by block index, further ones from the device cursor: no atomic
-    // traffic at all when there are fewer records than wavefronts
+    const uint32_t n_list = ENDS_ONLY ? W.counters[3] : W.counters[5];
     for (uint32_t round = 0;; round++) {
+        // ENDS_ONLY: cheap and even work, static striding.  Regular pass: first entry by block index, further
+        // ones from a device cursor (its list holds only the words that need a whole wavefront)
         uint32_t li = blockIdx.x;
-        if (round) {
+        if (ENDS_ONLY) {
+            li = blockIdx.x + round * gridDim.x;
+        } else if (round) {
             if (lane == 0) s_idx = gridDim.x + atomicAdd(&W.counters[1], 1u);
             __syncthreads();
             li = s_idx;
             __syncthreads();
         }
         if (li >= n_list) break;
-        const uint32_t idx = W.exc_long[li];
+        const uint32_t idx = ENDS_ONLY ? W.exc_long[li] : W.exc_wave[li];
         ExcRec rec = W.exc[idx];
         const int64_t ws = rec.ws;
         const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
@@ -1315,6 +1509,17 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
             continue;
         }
 
+        if (ENDS_ONLY) {
+            // length known now; hand the word to k_exc_quad (16 lanes per word, up to QUAD_UNITS units, byte mode
+            // with rank == symbol order) or to the regular pass (a wavefront per word)
+            if (lane == 0) {
+                W.exc[idx].len = (int32_t)nb;
+                const bool pfx_units = T.has_prefix && ws == ds && A.bytes[ws] != ' ';
+                const bool quad = T.is_byte_encoder && T.rank_is_sym && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
+                W.exc[idx].out_pos = quad ? 1 : 2;  // k_exc_split builds the two lists (out_pos is free until k_gather_exc)
+            }
+            continue;
+        }
         const bool docfirst = (ws == ds);
         const bool with_prefix = T.has_prefix && docfirst;
         const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
@@ -1642,7 +1847,11 @@ void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& 
     // words of at most 63 bytes, 64 per wavefront
     if (t.sym16) hipLaunchKernelGGL(k_exc_medium<uint16_t>, dim3(2560), dim3(64), 0, s, t, a, w);
     else hipLaunchKernelGGL(k_exc_medium<uint32_t>, dim3(1280), dim3(64), 0, s, t, a, w);
-    hipLaunchKernelGGL(k_exc, dim3(4096), dim3(64), 0, s, t, a, w);
+    // longer words: their ends first, then four per wavefront up to 256 units (byte mode), the rest one per wavefront
+    hipLaunchKernelGGL(k_exc<true>, dim3(4096), dim3(64), 0, s, t, a, w);
+    hipLaunchKernelGGL(k_exc_split, dim3(1024), dim3(64), 0, s, w);
+    hipLaunchKernelGGL(k_exc_quad, dim3(5120), dim3(64), 0, s, t, a, w);  // its list is empty outside byte mode
+    hipLaunchKernelGGL(k_exc<false>, dim3(4096), dim3(64), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const int64_t nb = (a.n_tiles + SCAN_BLOCK - 1) / SCAN_BLOCK;
