@@ -98,18 +98,18 @@ def initialize(model_or_path, *args, **kwargs):
 
 def _pack(texts):
     import numpy as np
-    chunks = []
+    try:
+        chunks = [t.encode("utf-8") for t in texts]  # a lone surrogate raises UnicodeEncodeError (reference: crash)
+    except AttributeError:
+        raise TypeError("bad argument type for built-in operation")
+    data = b"".join(chunks)
+    if b"\0" in data:  # rare: strdup() semantics of lib.c:770-772, a text ends at its first NUL
+        chunks = [b if (z := b.find(b"\0")) < 0 else b[:z] for b in chunks]
+        data = b"".join(chunks)
     offs = np.zeros(len(texts) + 1, dtype=np.int64)
-    for i, t in enumerate(texts):
-        if not isinstance(t, str):
-            raise TypeError("bad argument type for built-in operation")
-        b = t.encode("utf-8")  # a lone surrogate raises UnicodeEncodeError (reference: crash)
-        z = b.find(b"\0")
-        if z >= 0:
-            b = b[:z]  # strdup() semantics of lib.c:770-772
-        chunks.append(b)
-        offs[i + 1] = offs[i] + len(b)
-    return np.frombuffer(b"".join(chunks), dtype=np.uint8), offs
+    if chunks:
+        np.cumsum(np.fromiter(map(len, chunks), dtype=np.int64, count=len(chunks)), out=offs[1:])
+    return np.frombuffer(data, dtype=np.uint8), offs
 
 
 def _native_encode(text):
