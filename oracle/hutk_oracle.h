@@ -49,6 +49,16 @@ const char* hto_special(const hto_ctx* c, int idx);
 size_t hto_split_words(const uint8_t* text, size_t len, uint32_t* starts,
                        size_t cap);
 
+/* decode direction: one document's ids -> bytes (malloc'd, release with hto_free) */
+enum {
+    HTO_DEC_OK = 0,
+    HTO_DEC_RANGE = 1,     /* id < 0 or >= number of vocabulary lines: ValueError in the reference */
+    HTO_DEC_HOLE = 2,      /* no key has this id: undefined in the reference */
+    HTO_DEC_AMBIGUOUS = 3, /* two keys have this id: hash-map order decides in the reference */
+    HTO_DEC_NOMEM = 4
+};
+int hto_decode(const hto_ctx* c, const int32_t* ids, size_t n, uint8_t** out, size_t* out_len);
+
 /* one document; *ids_out is malloc'd (release with hto_free) */
 int hto_encode(const hto_ctx* c, const uint8_t* text, size_t len,
                int32_t** ids_out, size_t* n_out);

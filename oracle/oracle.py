@@ -59,6 +59,9 @@ def lib():
         L.hto_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t,
                                  C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_size_t)]
         L.hto_free.argtypes = [C.c_void_p]
+        L.hto_decode.restype = C.c_int
+        L.hto_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)),
+                                 C.POINTER(C.c_size_t)]
         L.hto_encode_batch.restype = C.c_int
         L.hto_encode_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_int, C.POINTER(C.POINTER(C.c_int32)),
@@ -147,6 +150,28 @@ class Oracle:
         """hutoken.encode(): an over-long word is not reported (lib.c:692-697)."""
         data = text.encode("utf-8") if isinstance(text, str) else bytes(text)
         return self.encode_bytes(data)[0]
+
+    def decode_bytes(self, ids):
+        """Decode direction (core.c:513-581): -> (bytes, status); status DEC_RANGE/HOLE/AMBIGUOUS as in the header."""
+        L = lib()
+        arr = np.ascontiguousarray(ids, dtype=np.int32)
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        st = L.hto_decode(self._h, arr.ctypes.data, len(arr), C.byref(p), C.byref(n))
+        out = bytes(bytearray(p[i] for i in range(n.value))) if st == 0 else b""
+        if st == 0:
+            L.hto_free(p)
+        return out, st
+
+    def decode(self, ids):
+        """hutoken.decode(): ValueError for ids out of range, the C string ends at its first NUL, then UTF-8."""
+        out, st = self.decode_bytes(ids)
+        if st == 1:
+            raise ValueError("Element must be non-negative and less than vocab size.")
+        if st:
+            raise RuntimeError(f"oracle decode status {st}")
+        z = out.find(b"\0")
+        return (out if z < 0 else out[:z]).decode("utf-8")
 
     def encode_packed(self, data, offsets, num_threads=1):
         """-> (ids int32 array, out_offsets int64 array, status int32 array)"""

@@ -95,3 +95,9 @@ class RefTokenizer:
 
     def batch_encode(self, texts, num_threads=1):
         return self.m.batch_encode(texts, num_threads)
+
+    def decode(self, ids):
+        return self.m.decode(ids)
+
+    def batch_decode(self, ids_lists, num_threads=1):
+        return self.m.batch_decode(ids_lists, num_threads)

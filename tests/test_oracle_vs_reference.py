@@ -87,6 +87,48 @@ def test_merges_file_degenerate_forms(tmp_path, oracle_mod):
         oracle_mod.Oracle(vp, spath, None, True, str(tmp_path / "missing.txt"))
 
 
+def _same_decode(orc, r, ids):
+    def run(f):
+        try:
+            return f(ids)
+        except Exception as e:  # noqa: BLE001
+            return ("raised", type(e).__name__)
+    a, b = run(r.decode), run(orc.decode)
+    assert a == b, (ids, a, b)
+
+
+def test_decode_direction(tmp_path, oracle_mod):
+    """decode (core.c:513-581, pretokenizer.c:197-296): byte mode and character mode with a prefix and
+    byte-fallback literals; round trips, arbitrary id sequences (invalid UTF-8 raises in both), ids out of
+    range.  Vocabularies with unique ids: with repeated ids the reference's table depends on its hash map."""
+    for seed in range(3):
+        ents, sp = H.random_byte_vocab(seed, n_merges=400, proper=seed != 1)
+        vp, spath = H.write_vocab(tmp_path, f"d{seed}", ents, sp)
+        orc = oracle_mod.Oracle(vp, spath, None, True)
+        r = ref.RefTokenizer(vp, spath, None, True)
+        rng = random.Random(seed * 31)
+        for _ in range(400):
+            t = H.random_text(rng)
+            ids = r.encode(t)
+            assert r.decode(ids) == t
+            _same_decode(orc, r, ids)
+        for _ in range(600):
+            _same_decode(orc, r, [rng.randrange(0, len(ents)) for _ in range(rng.randint(0, 10))])
+        for bad in ([-1], [len(ents)], [3, 10 ** 6]):
+            _same_decode(orc, r, bad)
+    for seed in range(2):
+        ents, sp = H.random_char_vocab(seed, n_merges=400)
+        vp, spath = H.write_vocab(tmp_path, f"dc{seed}", ents, sp)
+        orc = oracle_mod.Oracle(vp, spath, "▁", False)
+        r = ref.RefTokenizer(vp, spath, "▁", False)
+        rng = random.Random(seed * 17)
+        for _ in range(500):
+            ids = [x for x in r.encode(H.random_text(rng)) if x >= 0]
+            _same_decode(orc, r, ids)
+        for _ in range(600):
+            _same_decode(orc, r, [rng.randrange(0, len(ents)) for _ in range(rng.randint(0, 10))])
+
+
 def test_batch_threads_and_word_too_large(tmp_path, oracle_mod):
     ents, sp = H.random_byte_vocab(9, n_merges=100)
     vp, spath = H.write_vocab(tmp_path, "t", ents, sp)
