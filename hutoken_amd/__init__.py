@@ -193,9 +193,65 @@ def encode_packed_device(d_bytes, d_offsets, check=True):
     return ids, oo
 
 
+_NOT_INIT_DECODE = ("Vocabulary is not initialized for decoding. "
+                    "Call 'initialize_decode' function first.")
+
+
+def _ids_to_text(raw):
+    # PyUnicode_FromString (lib.c:938-939): the C string ends at its first 0x00, then strict UTF-8
+    z = raw.find(b"\0")
+    return (raw if z < 0 else raw[:z]).decode("utf-8")
+
+
+def _native_decode(tokens):
+    """_hutoken.decode (lib.c:876-951): list[int] -> str."""
+    import numpy as np
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT_DECODE)
+    if not isinstance(tokens, list):
+        raise TypeError("Argument must be a list of integers")
+    ids = np.asarray([int(t) for t in tokens], dtype=np.int64).astype(np.int32)  # (int)PyLong_AsLong
+    out, oo, _st = _ctx.decode_packed(ids, np.array([0, len(ids)], dtype=np.int64))
+    return _ids_to_text(out.tobytes())
+
+
+def _native_batch_decode(tokens, num_threads=1):
+    """_hutoken.batch_decode (lib.c:954-1126): list[list[int]] -> list[str]."""
+    import numpy as np
+    if _ctx is None:
+        raise RuntimeError(_NOT_INIT_DECODE)
+    if not isinstance(tokens, list):
+        raise TypeError("Failed to parse arguments. Expected a single list of tokens.")
+    if len(tokens) <= 0:
+        raise ValueError("No tokens provided.")
+    for item in tokens:
+        if not isinstance(item, list):
+            raise TypeError("Each item must be a list of integers.")
+    offs = np.zeros(len(tokens) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter(map(len, tokens), dtype=np.int64, count=len(tokens)), out=offs[1:])
+    flat = np.fromiter((int(t) for item in tokens for t in item), dtype=np.int64, count=int(offs[-1])).astype(np.int32)
+    out, oo, _st = _ctx.decode_packed(flat, offs)
+    raw = out.tobytes()
+    bounds = oo.tolist()
+    return [_ids_to_text(raw[bounds[i]:bounds[i + 1]]) for i in range(len(tokens))]
+
+
 def decode(tokens):
-    raise RuntimeError("hutoken: Error decoding tokens: hutoken_amd provides the encode direction only")
+    """hutoken.decode (reference hutoken.py:140-151)."""
+    try:
+        return _native_decode(tokens)
+    except ValueError as e:
+        traceback.print_exc(file=sys.stderr)
+        raise ValueError(f"hutoken: Error decoding tokens {tokens}: {e}")
+    except Exception as e:
+        traceback.print_exc(file=sys.stderr)
+        raise RuntimeError(f"hutoken: Error decoding tokens: {e}")
 
 
 def batch_decode(tokens, num_threads=1):
-    raise RuntimeError("hutoken: Error decoding tokens: hutoken_amd provides the encode direction only")
+    """hutoken.batch_decode (reference hutoken.py:153-160)."""
+    try:
+        return _native_batch_decode(tokens, num_threads)
+    except Exception as e:
+        traceback.print_exc(file=sys.stderr)
+        raise RuntimeError(f"hutoken: Error decoding tokens: {e}")

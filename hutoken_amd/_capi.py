@@ -17,7 +17,7 @@ DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
 EXPORTS = [
     "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
-    "hutk_host_free",
+    "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
     "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
 ]
@@ -48,6 +48,10 @@ def load(build_if_missing=True):
     L.hutk_ctx_create_merges.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]
     L.hutk_uses_merges.restype = i32
     L.hutk_uses_merges.argtypes = [vp]
+    L.hutk_decode_batch.restype = i32
+    L.hutk_decode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp]
+    L.hutk_decode_batch_device.restype = i32
+    L.hutk_decode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, vp]
     L.hutk_host_alloc.restype = vp
     L.hutk_host_alloc.argtypes = [C.c_size_t]
     L.hutk_host_free.restype = None
@@ -188,6 +192,30 @@ class Context:
         if rc not in (OK, E_WORD_TOO_LARGE):
             raise_for(rc)
         return ids[: int(oo[n])], oo, st[:n], rc
+
+    def decode_packed(self, ids, id_offsets):
+        """Decode direction, host numpy buffers: ids int32 + id_offsets int64[n+1] ->
+        (bytes uint8, out_offsets int64[n+1], status int32[n]).  Two calls: sizes, then the text."""
+        import numpy as np
+        L = load()
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        id_offsets = np.ascontiguousarray(id_offsets, dtype=np.int64)
+        n = len(id_offsets) - 1
+        oo = np.zeros(n + 1, dtype=np.int64)
+        st = np.zeros(max(n, 1), dtype=np.int32)
+        pid = ids.ctypes.data if len(ids) else None
+        raise_for(L.hutk_decode_batch(self._h, pid, id_offsets.ctypes.data, n, None, 0, oo.ctypes.data, st.ctypes.data))
+        total = int(oo[n])
+        out = np.empty(max(total, 1), dtype=np.uint8)
+        raise_for(L.hutk_decode_batch(self._h, pid, id_offsets.ctypes.data, n, out.ctypes.data, total, oo.ctypes.data,
+                                      st.ctypes.data))
+        return out[:total], oo, st[:n]
+
+    def decode_device(self, d_ids, d_id_offsets, n_docs, n_ids, d_bytes_out, bytes_cap, d_out_offsets, d_status,
+                      d_err, stream):
+        """Raw device pointers (ints); asynchronous on `stream`."""
+        raise_for(load().hutk_decode_batch_device(self._h, d_ids, d_id_offsets, n_docs, n_ids, d_bytes_out, bytes_cap,
+                                                  d_out_offsets, d_status, d_err, stream))
 
     def encode_one(self, data: bytes):
         """-> (ids list, return code)"""

@@ -82,6 +82,16 @@ struct hutk_ctx {
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
     DevBuf<uint32_t> w_exc_long, w_exc_quad, w_exc_wave;
+
+    // decode direction: tables and workspace
+    DevBuf<uint2> d_dec_ent, d_dec_sent;
+    DevBuf<uint8_t> d_dec_blob;
+    DecTables dec{};
+    DevBuf<uint32_t> dw_first, dw_count;
+    DevBuf<int64_t> dw_base;
+    DevBuf<int32_t> ds_ids, ds_status;
+    DevBuf<int64_t> ds_offs, ds_oo;
+    DevBuf<uint8_t> ds_bytes;
     DevBuf<int32_t> w_err;
 
     // staging for the host-buffer entry point
@@ -204,6 +214,27 @@ int upload_tables(hutk_ctx* c) {
         D.prefix_alone_syms = d_syms.p;
         d_n.release();
     }
+    // ---- decode direction ----
+    {
+        const size_t N = (size_t)T.dec_n;
+        std::vector<uint2> ent(N ? N : 1), sent;
+        for (size_t i = 0; i < N; i++) ent[i] = make_uint2(T.dec_off[i], (uint32_t)T.dec_len[i] | ((uint32_t)T.dec_flag[i] << 16));
+        HIP_TRY(c->d_dec_ent.reserve(ent.size()));
+        HIP_TRY(hipMemcpy(c->d_dec_ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        c->dec.sent = nullptr;
+        if (!T.dec_slen.empty()) {
+            sent.resize(N ? N : 1);
+            for (size_t i = 0; i < N; i++) sent[i] = make_uint2(T.dec_soff[i], (uint32_t)T.dec_slen[i]);
+            HIP_TRY(c->d_dec_sent.reserve(sent.size()));
+            HIP_TRY(hipMemcpy(c->d_dec_sent.p, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            c->dec.sent = c->d_dec_sent.p;
+        }
+        HIP_TRY(c->d_dec_blob.reserve(T.dec_blob.size() + 16));
+        HIP_TRY(hipMemcpy(c->d_dec_blob.p, T.dec_blob.data(), T.dec_blob.size(), hipMemcpyHostToDevice));
+        c->dec.ent = c->d_dec_ent.p;
+        c->dec.blob = c->d_dec_blob.p;
+        c->dec.n = T.dec_n;
+    }
     return HUTK_OK;
 }
 
@@ -270,7 +301,10 @@ void destroy(hutk_ctx* c) {
         c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
-        c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release(); c->w_err.release();
+        c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
+        c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
+        c->dw_count.release(); c->dw_base.release(); c->ds_ids.release(); c->ds_status.release();
+        c->ds_offs.release(); c->ds_oo.release(); c->ds_bytes.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
         for (int b = 0; b < 2; b++) {
@@ -590,6 +624,100 @@ int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets,
         if (!redo) return rc;
     }
     return encode_batch_simple(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
+}
+
+int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d_id_offsets, int64_t n_docs,
+                             int64_t n_ids, uint8_t* d_bytes_out, int64_t bytes_cap, int64_t* d_out_offsets,
+                             int32_t* d_status, int32_t* d_err, void* hip_stream) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to decode on");
+    if (n_docs < 0 || n_ids < 0 || !d_id_offsets || !d_out_offsets || (n_ids > 0 && !d_ids))
+        return set_err(HUTK_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const int64_t tile = dec_tile_ids();
+    const int64_t n_tiles = (n_ids + tile - 1) / tile;
+    if (n_tiles > 0x7FFFFFFFll) return set_err(HUTK_E_ARG, "batch too large");
+    HIP_TRY(c->dw_first.reserve((size_t)(n_ids / 32 + 4)));
+    HIP_TRY(c->dw_count.reserve((size_t)n_tiles + 8));
+    HIP_TRY(c->dw_base.reserve((size_t)n_tiles + n_tiles / 2048 + 16));
+    HIP_TRY(c->w_err.reserve(1));
+    DecArgs D{};
+    D.ids = d_ids;
+    D.id_offsets = d_id_offsets;
+    D.n_docs = n_docs;
+    D.n_ids = n_ids;
+    D.n_tiles = n_tiles;
+    D.bytes_out = d_bytes_out;
+    D.bytes_cap = bytes_cap;
+    D.out_offsets = d_out_offsets;
+    D.status = d_status;
+    D.err = d_err ? d_err : c->w_err.p;
+    D.first_bits = c->dw_first.p;
+    D.tile_count = c->dw_count.p;
+    D.tile_base = c->dw_base.p;
+    HIP_TRY(hipMemsetAsync(D.err, 0, 4, s));
+    HIP_TRY(hipMemsetAsync(D.first_bits, 0, (size_t)(n_ids / 32 + 4) * 4, s));
+    if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
+    if (n_tiles == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_offsets, 0, (size_t)(n_docs + 1) * 8, s));
+        return HUTK_OK;
+    }
+    launch_dec_mark(D, s);
+    launch_dec_sizes(c->dec, D, s);
+    {  // exclusive scan of the tile byte counts with the encode direction's scan kernels
+        BatchArgs A{};
+        A.n_tiles = n_tiles;
+        Workspace W{};
+        W.tile_count = D.tile_count;
+        W.tile_base = D.tile_base;
+        W.scan_part = c->dw_base.p + n_tiles + 2;
+        launch_scan(A, W, s);
+    }
+    launch_dec_write(c->dec, D, s);
+    HIP_TRY(hipGetLastError());
+    return HUTK_OK;
+}
+
+int hutk_decode_batch(hutk_ctx* c, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs, uint8_t* bytes_out,
+                      int64_t bytes_cap, int64_t* out_offsets, int32_t* status) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to decode on");
+    if (n_docs < 0 || !id_offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
+    if (id_offsets[0] != 0) return set_err(HUTK_E_ARG, "id_offsets[0] must be 0");
+    for (int64_t i = 0; i < n_docs; i++)
+        if (id_offsets[i + 1] < id_offsets[i]) return set_err(HUTK_E_ARG, "id_offsets must not decrease");
+    const int64_t n_ids = id_offsets[n_docs];
+    if (n_ids > 0 && !ids) return set_err(HUTK_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c->ds_ids.reserve((size_t)n_ids + 16));
+    HIP_TRY(c->ds_offs.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->ds_oo.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->ds_status.reserve((size_t)n_docs + 1));
+    HIP_TRY(c->w_err.reserve(1));
+    if (bytes_out && bytes_cap > 0) HIP_TRY(c->ds_bytes.reserve((size_t)bytes_cap + 16));
+    if (n_ids) HIP_TRY(hipMemcpyAsync(c->ds_ids.p, ids, (size_t)n_ids * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->ds_offs.p, id_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    int rc = hutk_decode_batch_device(c, c->ds_ids.p, c->ds_offs.p, n_docs, n_ids, bytes_out ? c->ds_bytes.p : nullptr,
+                                      bytes_cap, c->ds_oo.p, c->ds_status.p, c->w_err.p, s);
+    if (rc) return rc;
+    int32_t err = 0;
+    HIP_TRY(hipMemcpyAsync(out_offsets, c->ds_oo.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&err, c->w_err.p, 4, hipMemcpyDeviceToHost, s));
+    if (status && n_docs) HIP_TRY(hipMemcpyAsync(status, c->ds_status.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (bytes_out && err == HUTK_OK && out_offsets[n_docs] > 0)
+        HIP_TRY(hipMemcpy(bytes_out, c->ds_bytes.p, (size_t)out_offsets[n_docs], hipMemcpyDeviceToHost));
+    switch (err) {
+        case HUTK_OK: return HUTK_OK;
+        case HUTK_E_VALUE: return set_err(err, "Element must be non-negative and less than vocab size.");
+        case HUTK_E_UNSUPPORTED:
+            return set_err(err, "a token cannot be decoded on its own (id without a unique key, or a token that ends "
+                                "inside a special value or a character)");
+        case HUTK_E_CAPACITY: return set_err(err, "bytes_cap too small");
+        default: return set_err(err, "device-side failure");
+    }
 }
 
 void* hutk_host_alloc(size_t n_bytes) {

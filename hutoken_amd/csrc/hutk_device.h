@@ -107,6 +107,32 @@ struct BatchArgs {
     int32_t* err;     // never null (workspace word when the caller passes none)
 };
 
+// ---- decode direction (hutk_decode.hip) ----
+constexpr uint32_t DEC_BAD_DEV = 0xFFFFu, DEC_NOSTRIP_DEV = 0xFFFEu, DEC_FD_PFX_PARTIAL = 8u;
+struct DecTables {
+    const uint2* ent;     // [n] x: offset into blob, y: output length (DEC_BAD_DEV: cannot be decoded) | flags << 16
+    const uint2* sent;    // [n] the same with the prefix stripped from the token's front, or null (no prefix)
+    const uint8_t* blob;  // output bytes
+    int64_t n;            // ids 0..n-1 are in range (number of vocabulary lines, lib.c:377)
+};
+struct DecArgs {
+    const int32_t* ids;
+    const int64_t* id_offsets;  // [n_docs + 1]
+    int64_t n_docs, n_ids, n_tiles;
+    uint8_t* bytes_out;         // null: sizes and offsets only
+    int64_t bytes_cap;
+    int64_t* out_offsets;       // [n_docs + 1]
+    int32_t* status;            // may be null
+    int32_t* err;
+    uint32_t* first_bits;       // [n_ids / 32 + 2] bit i: token i is the first of a document
+    uint32_t* tile_count;       // [n_tiles] bytes per tile of ids
+    int64_t* tile_base;         // [n_tiles + 1] their exclusive scan
+};
+int64_t dec_tile_ids();
+void launch_dec_mark(const DecArgs& d, hipStream_t s);
+void launch_dec_sizes(const DecTables& t, const DecArgs& d, hipStream_t s);
+void launch_dec_write(const DecTables& t, const DecArgs& d, hipStream_t s);
+
 // hutk_kernels.hip
 void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s);

@@ -159,6 +159,26 @@ struct Tables {
     bool id_path = false;
     bool prefix_alone_final = false;
     std::vector<int32_t> prefix_alone_ids;
+
+    // ---- decode direction (core.c:513-581, pretokenizer.c:197-296) ----
+    // Per id < dec_n (the number of vocabulary lines, lib.c:377): its output bytes when the token is decoded
+    // on its own.  That is exact in any context when the scan of pretokenizer_decode, started at the token's
+    // first byte, ends exactly at its last one and never stops on a proper prefix of a longer special value.
+    // Tokens for which this cannot be promised carry a flag and make their document fail loudly.
+    int64_t dec_n = 0;
+    std::vector<uint8_t> dec_blob;    // output bytes of all tokens, then (prefix mode) of their stripped forms
+    std::vector<uint32_t> dec_off;    // [dec_n] into dec_blob
+    std::vector<uint16_t> dec_len;    // [dec_n] output length; DEC_BAD for ids that cannot be decoded
+    std::vector<uint32_t> dec_soff;   // prefix mode: the same with the prefix removed from the token's front
+    std::vector<uint16_t> dec_slen;   //   DEC_NOSTRIP: the token does not start with the prefix
+    std::vector<uint8_t> dec_flag;    // DEC_F_* bits
+};
+constexpr uint16_t DEC_BAD = 0xFFFFu, DEC_NOSTRIP = 0xFFFEu;
+enum : uint8_t {
+    DEC_F_HOLE = 1,        // no key has this id (undefined behaviour in the reference)
+    DEC_F_AMBIGUOUS = 2,   // several keys have this id (the reference keeps whichever its hash map yields last)
+    DEC_F_CONTEXT = 4,     // decoding depends on the neighbouring tokens (see above)
+    DEC_F_PFX_PARTIAL = 8  // the token is a proper prefix of the prefix string: stripping may span tokens
 };
 
 struct LoadError {

@@ -54,7 +54,7 @@ bool hex_field_to_bytes(const char* s, const char* end, std::string& out) {
     return true;
 }
 
-LoadError read_vocab(const char* path, std::unordered_map<std::string, int32_t>& vocab) {
+LoadError read_vocab(const char* path, std::unordered_map<std::string, int32_t>& vocab, int64_t* n_lines) {
     File f(fopen(path, "rb"));
     if (!f) return fail(HUTK_E_FILE_NOT_FOUND, "Could not open vocab file.");
     std::string data;
@@ -89,10 +89,12 @@ LoadError read_vocab(const char* path, std::unordered_map<std::string, int32_t>&
         ++lines;
     }
     if (lines == 0) return fail(HUTK_E_VALUE, "Vocab file is empty.");
+    *n_lines = (int64_t)lines;
     return {};
 }
 
-LoadError read_special(const char* path, std::string special[256], bool has[256]) {
+LoadError read_special(const char* path, std::string special[256], bool has[256], int seq[256]) {
+    int n_loaded = 0;
     File f(fopen(path, "r"));
     if (!f) return fail(HUTK_E_FILE_NOT_FOUND, "Could not open special characters file.");
     char buf[32];  // lib.c:483: records are 31-character fgets() chunks
@@ -113,6 +115,7 @@ LoadError read_special(const char* path, std::string special[256], bool has[256]
         if (vlen < 2) return fail(HUTK_E_VALUE, "Failed to convert hex string to ASCII.");
         special[idx].assign(vs, vlen - 1);
         has[idx] = true;
+        seq[idx] = ++n_loaded;  // decode: among equal values the one loaded last names the byte
     }
     return {};
 }
@@ -562,21 +565,130 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
     return {};
 }
 
+
+// ------------------------------------------------------------------------
+// decode direction: per-token output bytes (see Tables::dec_*)
+// ------------------------------------------------------------------------
+void build_decode_tables(const std::unordered_map<std::string, int32_t>& vocab, int64_t n_lines,
+                         const std::string special[256], const bool has_special[256], const int seq[256],
+                         const char* prefix, bool is_byte_encoder, Tables& T) {
+    T.dec_n = n_lines;
+    const size_t N = (size_t)n_lines;
+    std::vector<const std::string*> key(N, nullptr);
+    T.dec_flag.assign(N, DEC_F_HOLE);
+    for (auto& kv : vocab) {
+        if (kv.second < 0 || (int64_t)kv.second >= n_lines) continue;
+        uint8_t& f = T.dec_flag[(size_t)kv.second];
+        if (key[(size_t)kv.second]) f |= DEC_F_AMBIGUOUS;
+        key[(size_t)kv.second] = &kv.first;
+        f &= (uint8_t)~DEC_F_HOLE;
+    }
+    // one scan step of pretokenizer_decode at s[p]: *adv bytes consumed, output appended to out.  *context:
+    // the step would depend on bytes after the end of s (a longer special value could still match, or the
+    // character is cut off).
+    auto step = [&](const std::string& s, size_t p, std::string& out, size_t* adv, bool* context) {
+        size_t best_len = 0;
+        int best_idx = -1, best_seq = -1;
+        const size_t rest = s.size() - p;
+        for (int i = 0; i < 256; i++) {
+            if (!has_special[i] || special[i].empty()) continue;
+            const std::string& v = special[i];
+            if (v.size() <= rest) {
+                if (s.compare(p, v.size(), v) != 0) continue;
+                if (v.size() > best_len || (v.size() == best_len && seq[i] > best_seq)) {
+                    best_len = v.size();
+                    best_idx = i;
+                    best_seq = seq[i];
+                }
+            } else if (v.compare(0, rest, s, p, rest) == 0) {
+                *context = true;  // the rest of the token is a proper prefix of this value
+            }
+        }
+        if (best_idx >= 0) {
+            out.push_back((char)best_idx);
+            *adv = best_len;
+            return;
+        }
+        const unsigned char b = (unsigned char)s[p];
+        size_t l = (size_t)lead_len(b);
+        const bool bad_lead = b >= 0x80 && l == 1;
+        if (!bad_lead && p + l > s.size()) {
+            *context = true;
+            l = s.size() - p;
+        }
+        if (is_byte_encoder) {  // pretokenizer.c:236-246
+            // utf8_to_codepoint (pretokenizer.c:175-195): plain bit arithmetic, no validation
+            auto at = [&](size_t q) -> uint32_t { return q < s.size() ? (unsigned char)s[q] : 0u; };
+            uint32_t cp = 0xFFFD;
+            if (b < 0x80) cp = b;
+            else if ((b & 0xE0) == 0xC0) cp = ((b & 0x1Fu) << 6) | (at(p + 1) & 0x3Fu);
+            else if ((b & 0xF0) == 0xE0) cp = ((b & 0x0Fu) << 12) | ((at(p + 1) & 0x3Fu) << 6) | (at(p + 2) & 0x3Fu);
+            else if ((b & 0xF8) == 0xF0)
+                cp = ((b & 0x07u) << 18) | ((at(p + 1) & 0x3Fu) << 12) | ((at(p + 2) & 0x3Fu) << 6) | (at(p + 3) & 0x3Fu);
+            out.push_back(cp < 256 ? (char)cp : '?');
+        } else {
+            out.append(s, p, l);
+        }
+        *adv = l;
+    };
+    auto decode_alone = [&](const std::string& s, size_t from, std::string& out) -> bool {
+        bool context = false;
+        out.clear();
+        for (size_t p = from; p < s.size();) {
+            size_t adv = 1;
+            step(s, p, out, &adv, &context);
+            p += adv ? adv : 1;
+        }
+        return context;
+    };
+    const std::string pfx = (prefix && prefix[0]) ? std::string(prefix) : std::string();
+    T.dec_off.assign(N, 0);
+    T.dec_len.assign(N, DEC_BAD);
+    if (!pfx.empty()) {
+        T.dec_soff.assign(N, 0);
+        T.dec_slen.assign(N, DEC_NOSTRIP);
+    }
+    std::string out;
+    for (size_t id = 0; id < N; id++) {
+        if (!key[id] || (T.dec_flag[id] & DEC_F_AMBIGUOUS)) continue;
+        const std::string& k = *key[id];
+        if (decode_alone(k, 0, out)) T.dec_flag[id] |= DEC_F_CONTEXT;
+        if (out.size() >= DEC_NOSTRIP) continue;  // cannot happen with 2047-byte keys; stays DEC_BAD
+        T.dec_off[id] = (uint32_t)T.dec_blob.size();
+        T.dec_len[id] = (uint16_t)out.size();
+        T.dec_blob.insert(T.dec_blob.end(), out.begin(), out.end());
+        if (!pfx.empty()) {
+            if (k.size() >= pfx.size() && k.compare(0, pfx.size(), pfx) == 0) {
+                if (decode_alone(k, pfx.size(), out)) T.dec_flag[id] |= DEC_F_CONTEXT;
+                T.dec_soff[id] = (uint32_t)T.dec_blob.size();
+                T.dec_slen[id] = (uint16_t)out.size();
+                T.dec_blob.insert(T.dec_blob.end(), out.begin(), out.end());
+            } else if (k.size() < pfx.size() && pfx.compare(0, k.size(), k) == 0) {
+                T.dec_flag[id] |= DEC_F_PFX_PARTIAL;
+            }
+        }
+    }
+    T.dec_blob.resize(T.dec_blob.size() + 16, 0);  // 16-byte reads at a token's offset stay inside
+}
+
 }  // namespace
 
 LoadError load_tables(const char* vocab_path, const char* special_path, const char* prefix,
                       bool is_byte_encoder, const char* merges_path, Tables& T) {
     std::unordered_map<std::string, int32_t> vocab;
-    LoadError e = read_vocab(vocab_path, vocab);
+    int64_t n_lines = 0;
+    LoadError e = read_vocab(vocab_path, vocab, &n_lines);
     if (e.code) return e;
     std::string special[256];
     bool has_special[256] = {false};
-    e = read_special(special_path, special, has_special);
+    int special_seq[256] = {0};
+    e = read_special(special_path, special, has_special, special_seq);
     if (e.code) return e;
 
     T = Tables();
     T.is_byte_encoder = is_byte_encoder;
     T.n_keys = (int64_t)vocab.size();
+    build_decode_tables(vocab, n_lines, special, has_special, special_seq, prefix, is_byte_encoder, T);
     if (merges_path) {
         // a merges file switches the reference to its id-keyed merge loop -- unless the file has no countable
         // line, in which case no merges map exists and the string path below stays in force (lib.c:592, core.c:457)

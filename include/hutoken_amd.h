@@ -47,7 +47,11 @@ enum {
                                     reference reports NOTHING for it (core.c:503 clears the
                                     message again) and ends the document there; so does
                                     hutk_encode_batch: the ids are those before that word */
-    HUTK_DOC_INVALID_UTF8 = 2
+    HUTK_DOC_INVALID_UTF8 = 2,
+    /* decode direction */
+    HUTK_DOC_ID_OUT_OF_RANGE = 3, /* an id < 0 or >= the number of vocabulary lines (src/core.c:523-531) */
+    HUTK_DOC_ID_UNDECODABLE = 4   /* an id without a unique key, or a token whose decoding depends on its
+                                     neighbours (see hutk_decode_batch) */
 };
 
 /* Replaces _hutoken.initialize(vocab_file_path, special_file_path, prefix,
@@ -122,6 +126,27 @@ void hutk_host_free(void* p);
 /* Replaces p_encode, src/lib.c:668-720 (one document on the calling thread). */
 int hutk_encode(hutk_ctx* ctx, const uint8_t* text, int64_t len, int32_t* ids_out,
                 int64_t ids_cap, int64_t* n_ids, int32_t* status);
+
+/* Decode direction.  Replaces the worker pool of p_batch_decode / p_decode (src/lib.c:876-1126): one
+ * decode(struct DecodeTask*) per document (src/core.c:513-581: token strings concatenated, then
+ * pretokenizer_decode, src/pretokenizer.c:197-296: prefix stripped from the front, special values mapped
+ * back to their bytes by longest match, other characters to the byte of their code point (byte-encoder
+ * mode, '?' above 255) or copied).
+ * ids[id_offsets[d] .. id_offsets[d+1]) are the tokens of document d; the decoded BYTES of document d are
+ * bytes_out[out_offsets[d] .. out_offsets[d+1]) (the Python layer cuts at the first 0x00 and decodes UTF-8
+ * like PyUnicode_FromString, lib.c:938-939).  bytes_out == NULL: only out_offsets (hence the sizes) and
+ * status are produced; call again with out_offsets[n_docs] bytes of room.
+ * Returns HUTK_E_VALUE when an id is out of range (the reference's ValueError "Element must be
+ * non-negative and less than vocab size.") and HUTK_E_UNSUPPORTED when a token cannot be decoded on its
+ * own: an id that no key or several keys carry (uninitialised memory / hash-map order in the reference),
+ * or a token that ends inside a longer special value or inside a character (its decoding would depend
+ * on the next token).  status[] names the documents. */
+int hutk_decode_batch(hutk_ctx* ctx, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs,
+                      uint8_t* bytes_out, int64_t bytes_cap, int64_t* out_offsets, int32_t* status);
+/* The same on device-resident buffers, asynchronously on `hip_stream`; *d_err receives the error code. */
+int hutk_decode_batch_device(hutk_ctx* ctx, const int32_t* d_ids, const int64_t* d_id_offsets,
+                             int64_t n_docs, int64_t n_ids, uint8_t* d_bytes_out, int64_t bytes_cap,
+                             int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err, void* hip_stream);
 
 /* Introspection (tests, bench). */
 int64_t hutk_vocab_size(const hutk_ctx* ctx);      /* distinct keys loaded */
