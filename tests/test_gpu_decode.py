@@ -107,3 +107,35 @@ def test_python_surface(vg_files, oracle_mod):
         hutoken.batch_decode([])
     with pytest.raises(RuntimeError, match="Each item must be a list of integers"):
         hutoken.batch_decode([1, 2])
+
+
+def test_g6_golden(tmp_path):
+    """Against the committed outputs of the reference's own decode() (tests/golden/g6_decode.json)."""
+    import hashlib
+    import json
+    import os
+    import hutoken_amd as hutoken
+    for g in json.load(open(os.path.join(H.GOLDEN_DIR, "g6_decode.json"))):
+        if g["mode"] == "byte":
+            ents, sp = H.random_byte_vocab(g["seed"], n_merges=1500, proper=g["proper"])
+            prefix, is_byte = None, True
+        else:
+            ents, sp = H.random_char_vocab(g["seed"], n_merges=1500)
+            prefix, is_byte = "▁", False
+        vp, spath = H.write_vocab(tmp_path, "g6_%d" % g["seed"], ents, sp)
+        hutoken.initialize(vp, spath, prefix=prefix, is_byte_encoder=is_byte)
+        rng = random.Random(g["seed"] * 1000)
+        h = hashlib.sha256()
+        for k in range(g["n"]):
+            if k % 2 == 0:
+                ids = [x for x in hutoken.encode(H.random_text(rng, max_words=20)) if x >= 0]
+            else:
+                ids = [rng.randrange(0, len(ents)) for _ in range(rng.randint(0, 24))]
+            try:
+                res = hutoken._native_decode(ids)
+            except Exception as e:  # noqa: BLE001
+                res = {"raises": type(e).__name__}
+            if k < len(g["first"]):
+                assert [ids, res] == g["first"][k]
+            h.update(json.dumps([ids, res], ensure_ascii=True).encode())
+        assert h.hexdigest() == g["sha256"]

@@ -104,3 +104,38 @@ def test_g5_merges_path(tmp_path, oracle_mod):
         assert res[:len(g["first"])] == g["first"]
         assert sum(len(x) for x in res) == g["n_ids"]
         assert sha_ids(res) == g["sha256"]
+
+
+def _g6_cases(g, tmp_path):
+    import json as _json
+    if g["mode"] == "byte":
+        ents, sp = H.random_byte_vocab(g["seed"], n_merges=1500, proper=g["proper"])
+        prefix, is_byte = None, True
+    else:
+        ents, sp = H.random_char_vocab(g["seed"], n_merges=1500)
+        prefix, is_byte = "▁", False
+    vp, spath = H.write_vocab(tmp_path, "g6_%d" % g["seed"], ents, sp)
+    return vp, spath, prefix, is_byte, len(ents)
+
+
+def test_g6_decode(tmp_path, oracle_mod):
+    """Decode direction against the reference's outputs (texts, or the exception an invalid result raises)."""
+    import json as _json
+    for g in load("g6_decode.json"):
+        vp, spath, prefix, is_byte, n = _g6_cases(g, tmp_path)
+        orc = oracle_mod.Oracle(vp, spath, prefix, is_byte)
+        rng = random.Random(g["seed"] * 1000)
+        h = hashlib.sha256()
+        for k in range(g["n"]):
+            if k % 2 == 0:
+                ids = [x for x in orc.encode(H.random_text(rng, max_words=20)) if x >= 0]
+            else:
+                ids = [rng.randrange(0, n) for _ in range(rng.randint(0, 24))]
+            try:
+                res = orc.decode(ids)
+            except Exception as e:  # noqa: BLE001
+                res = {"raises": type(e).__name__}
+            if k < len(g["first"]):
+                assert [ids, res] == g["first"][k]
+            h.update(_json.dumps([ids, res], ensure_ascii=True).encode())
+        assert h.hexdigest() == g["sha256"]

@@ -15,6 +15,8 @@ bit-for-bit) and the reference's outputs.  Run in the build container only.
       merges file whose rule order is unrelated to the ids (helpers.random_merges_text: comments,
       skipped rules, repeated pairs, CRLF), with and without a prefix, x 1500 seeded texts; VG with
       its merges file x 2000 docs of C3                       -> same
+  G6  the DECODE direction: mid vocabularies (byte mode proper / shuffled ids, character mode with prefix)
+      x 1200 id sequences each (round trips and random ids)   -> text or exception of the first 60 + sha256
 """
 import hashlib
 import json
@@ -119,6 +121,41 @@ def g5(tmp):
     return out
 
 
+def g6(tmp):
+    """Decode direction: the reference's own decode() on seeded id sequences.  Unique-id vocabularies (with
+    repeated ids the reference's table depends on its hash map).  Results that are not valid UTF-8 are recorded
+    as the exception they raise."""
+    out = []
+    for seed, proper, mode in [(31, True, "byte"), (32, False, "byte"), (33, True, "char")]:
+        if mode == "byte":
+            ents, sp = H.random_byte_vocab(seed, n_merges=1500, proper=proper)
+            prefix, is_byte = None, True
+        else:
+            ents, sp = H.random_char_vocab(seed, n_merges=1500)
+            prefix, is_byte = "▁", False
+        vp, spath = H.write_vocab(tmp, f"g6_{seed}", ents, sp)
+        r = ref.RefTokenizer(vp, spath, prefix, is_byte)
+        rng = random.Random(seed * 1000)
+        cases = []
+        for k in range(1200):
+            if k % 2 == 0:
+                ids = [x for x in r.encode(H.random_text(rng, max_words=20)) if x >= 0]
+            else:
+                ids = [rng.randrange(0, len(ents)) for _ in range(rng.randint(0, 24))]
+            try:
+                res = r.decode(ids)
+            except Exception as e:  # noqa: BLE001
+                res = {"raises": type(e).__name__}
+            cases.append((ids, res))
+        h = hashlib.sha256()
+        for ids, res in cases:
+            h.update(json.dumps([ids, res], ensure_ascii=True).encode())
+        out.append({"seed": seed, "proper": proper, "mode": mode, "first": cases[:60], "n": len(cases),
+                    "sha256": h.hexdigest(),
+                    "recipe": "even k: ids of helpers.random_text(rng, max_words=20) without -1; odd k: random ids"})
+    return out
+
+
 def corpus_case(tok, name, n_docs, nfirst=48):
     d, o = synth.corpus(name, n_docs)
     docs = synth.docs_as_str(d, o)
@@ -134,6 +171,9 @@ def main():
     if "--only-g5" in sys.argv:
         json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
         return
+    if "--only-g6" in sys.argv:
+        json.dump(g6(tmp), open(os.path.join(OUT, "g6_decode.json"), "w"), ensure_ascii=True)
+        return
     json.dump(g1(tmp), open(os.path.join(OUT, "g1_handpicked.json"), "w"), ensure_ascii=True, indent=0)
     json.dump(g2(tmp), open(os.path.join(OUT, "g2_mid_vocabs.json"), "w"))
     vp, sp, kw = data.vocab_files("VG")
@@ -146,6 +186,7 @@ def main():
     g4 = [corpus_case(r, "C5", 3000), corpus_case(r, "C3", 2000)]
     json.dump(g4, open(os.path.join(OUT, "g4_vl_corpora.json"), "w"))
     json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
+    json.dump(g6(tmp), open(os.path.join(OUT, "g6_decode.json"), "w"), ensure_ascii=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
