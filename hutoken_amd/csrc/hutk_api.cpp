@@ -88,7 +88,7 @@ struct hutk_ctx {
     DevBuf<uint8_t> d_dec_blob;
     DecTables dec{};
     DevBuf<uint32_t> dw_first, dw_count;
-    DevBuf<int64_t> dw_base;
+    DevBuf<int64_t> dw_base, dw_tfd;
     DevBuf<int32_t> ds_ids, ds_status;
     DevBuf<int64_t> ds_offs, ds_oo;
     DevBuf<uint8_t> ds_bytes;
@@ -303,7 +303,7 @@ void destroy(hutk_ctx* c) {
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
         c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
-        c->dw_count.release(); c->dw_base.release(); c->ds_ids.release(); c->ds_status.release();
+        c->dw_count.release(); c->dw_base.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
         c->ds_offs.release(); c->ds_oo.release(); c->ds_bytes.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
@@ -641,6 +641,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     HIP_TRY(c->dw_first.reserve((size_t)(n_ids / 32 + 4)));
     HIP_TRY(c->dw_count.reserve((size_t)n_tiles + 8));
     HIP_TRY(c->dw_base.reserve((size_t)n_tiles + n_tiles / 2048 + 16));
+    HIP_TRY(c->dw_tfd.reserve((size_t)n_tiles + 1));
     HIP_TRY(c->w_err.reserve(1));
     DecArgs D{};
     D.ids = d_ids;
@@ -656,14 +657,17 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     D.first_bits = c->dw_first.p;
     D.tile_count = c->dw_count.p;
     D.tile_base = c->dw_base.p;
+    D.tile_first_doc = c->dw_tfd.p;
     HIP_TRY(hipMemsetAsync(D.err, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(D.first_bits, 0, (size_t)(n_ids / 32 + 4) * 4, s));
+    const bool strip = c->dec.sent != nullptr;  // the first-token bitmap is only needed to strip a prefix
+    if (strip) HIP_TRY(hipMemsetAsync(D.first_bits, 0, (size_t)(n_ids / 32 + 4) * 4, s));
+    else D.first_bits = nullptr;
     if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
     if (n_tiles == 0) {
         HIP_TRY(hipMemsetAsync(d_out_offsets, 0, (size_t)(n_docs + 1) * 8, s));
         return HUTK_OK;
     }
-    launch_dec_mark(D, s);
+    if (strip) launch_dec_mark(D, s);
     launch_dec_sizes(c->dec, D, s);
     {  // exclusive scan of the tile byte counts with the encode direction's scan kernels
         BatchArgs A{};

@@ -38,6 +38,30 @@ __device__ __forceinline__ int64_t dec_doc_of(const DecArgs& D, int64_t i) {
 }
 
 constexpr int DEC_THREADS = 256, DEC_PER_THREAD = 8, DEC_TILE = DEC_THREADS * DEC_PER_THREAD;
+
+// first document whose first token is at or after the tile's first token (binary search, once per tile)
+__global__ void k_dec_pre(DecArgs D) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= D.n_tiles) return;
+    const int64_t t0 = t * DEC_TILE;
+    int64_t lo = 0, hi = D.n_docs + 1;  // first d in [0, n_docs] with id_offsets[d] >= t0
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (D.id_offsets[mid] < t0) lo = mid + 1; else hi = mid;
+    }
+    D.tile_first_doc[t] = lo;
+}
+
+// inclusive prefix sum over the 64 lanes of a wavefront (DPP row shifts and broadcasts)
+__device__ __forceinline__ uint32_t dec_wave_incl(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
 constexpr int DEC_LDS_BYTES = 24 * 1024;  // text of one tile staged for coalesced stores (mean ~8 KB)
 
 // token i of the batch: (offset into the blob, output length); errors are reported here
@@ -69,7 +93,8 @@ __device__ __forceinline__ uint2 dec_entry(const DecTables& T, const DecArgs& D,
 
 template <bool WRITE>
 __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs D) {
-    __shared__ uint32_t s_part[DEC_THREADS];
+    __shared__ uint32_t s_part[DEC_THREADS / 64];
+    __shared__ uint16_t s_pref[WRITE ? DEC_TILE : 2];  // bytes of the tile before each of its tokens
     __shared__ __attribute__((aligned(16))) uint8_t s_text[WRITE ? DEC_LDS_BYTES : 16];
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -77,7 +102,7 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
     uint32_t off[DEC_PER_THREAD], len[DEC_PER_THREAD];
     uint32_t firsts = 0;  // bit k: token i0 + k starts a document
     {
-        const uint32_t w = (i0 < D.n_ids) ? D.first_bits[i0 >> 5] : 0u;  // DEC_PER_THREAD = 8 divides 32
+        const uint32_t w = (D.first_bits && i0 < D.n_ids) ? D.first_bits[i0 >> 5] : 0u;  // DEC_PER_THREAD = 8 divides 32
         firsts = (w >> (i0 & 31)) & 0xFFu;
     }
     uint32_t mine = 0;
@@ -93,37 +118,40 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
         }
         mine += len[k];
     }
-    // block exclusive scan of the per-thread byte counts
-    s_part[tid] = mine;
+    // block exclusive scan of the per-thread byte counts: DPP scan per wavefront, then the four wave totals
+    const uint32_t incl = dec_wave_incl(mine);
+    if ((tid & 63) == 63) s_part[tid >> 6] = incl;
     __syncthreads();
-    for (int o = 1; o < DEC_THREADS; o <<= 1) {
-        const uint32_t v = (tid >= o) ? s_part[tid - o] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < DEC_THREADS / 64; w++) {
+        const uint32_t t = s_part[w];
+        if (w < (tid >> 6)) wave_base += t;
+        total += t;
     }
-    const uint32_t total = s_part[DEC_THREADS - 1];
-    uint32_t before = s_part[tid] - mine;
+    uint32_t before = wave_base + incl - mine;
     if (!WRITE) {
         if (tid == 0) D.tile_count[tile] = total;
         return;
     }
     const int64_t g0 = D.tile_base[tile];  // byte offset of the tile's text in the output
-    // out_offsets of the documents that start in this tile
+    // bytes before each token of the tile, then out_offsets of the documents whose first token is in the tile
+    // (consecutive documents from tile_first_doc on, empty ones included; coalesced reads of id_offsets)
     {
         uint32_t pos = before;
 #pragma unroll
         for (int k = 0; k < DEC_PER_THREAD; k++) {
-            if ((firsts >> k) & 1u) {
-                const int64_t i = i0 + k;
-                int64_t d = dec_doc_of(D, i);  // the non-empty document that starts at i ...
-                for (;;) {                     // ... and the empty ones right before it
-                    D.out_offsets[d] = g0 + pos;
-                    if (d == 0 || D.id_offsets[d - 1] != i) break;
-                    d--;
-                }
-            }
+            s_pref[tid * DEC_PER_THREAD + k] = (uint16_t)pos;
             pos += len[k];
+        }
+    }
+    __syncthreads();
+    {
+        const int64_t t0 = tile * DEC_TILE, t1 = t0 + DEC_TILE;
+        for (int64_t d = D.tile_first_doc[tile] + tid; d < D.n_docs; d += DEC_THREADS) {
+            const int64_t i = D.id_offsets[d];
+            if (i >= t1 || i >= D.n_ids) break;
+            D.out_offsets[d] = g0 + s_pref[i - t0];
         }
     }
     if (!D.bytes_out) return;
@@ -132,12 +160,27 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
         return;
     }
     const uint32_t shift = (uint32_t)(g0 & 15);  // LDS index and global address agree modulo 16
-    if (total + shift <= (uint32_t)DEC_LDS_BYTES) {
+    if (total + shift <= (uint32_t)DEC_LDS_BYTES) {  // (always < 65536: s_pref holds 16-bit positions)
+        // the first 16 bytes of all eight tokens are loaded before any is used (entries are 4-byte aligned and
+        // the blob has 16 bytes of slack): one round trip per thread, not one per byte
+        uint4 v[DEC_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < DEC_PER_THREAD; k++)
+            v[k] = len[k] ? *reinterpret_cast<const uint4*>(T.blob + off[k]) : make_uint4(0, 0, 0, 0);
         uint32_t pos = before + shift;
 #pragma unroll
         for (int k = 0; k < DEC_PER_THREAD; k++) {
-            const uint8_t* src = T.blob + off[k];
-            for (uint32_t j = 0; j < len[k]; j++) s_text[pos + j] = src[j];
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((uint32_t)j < len[k]) s_text[pos + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+            if (len[k] > 8) {
+#pragma unroll
+                for (int j = 8; j < 16; j++)
+                    if ((uint32_t)j < len[k]) s_text[pos + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                const uint8_t* src = T.blob + off[k];
+                for (uint32_t j = 16; j < len[k]; j++) s_text[pos + j] = src[j];
+            }
             pos += len[k];
         }
         __syncthreads();
@@ -175,6 +218,7 @@ void launch_dec_mark(const DecArgs& d, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_mark, dim3((unsigned)((d.n_docs + 255) / 256)), dim3(256), 0, s, d);
 }
 void launch_dec_sizes(const DecTables& t, const DecArgs& d, hipStream_t s) {
+    hipLaunchKernelGGL(k_dec_pre, dim3((unsigned)((d.n_tiles + 255) / 256)), dim3(256), 0, s, d);
     hipLaunchKernelGGL(k_dec_tiles<false>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
 }
 void launch_dec_write(const DecTables& t, const DecArgs& d, hipStream_t s) {

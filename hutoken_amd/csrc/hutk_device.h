@@ -127,6 +127,7 @@ struct DecArgs {
     uint32_t* first_bits;       // [n_ids / 32 + 2] bit i: token i is the first of a document
     uint32_t* tile_count;       // [n_tiles] bytes per tile of ids
     int64_t* tile_base;         // [n_tiles + 1] their exclusive scan
+    int64_t* tile_first_doc;    // [n_tiles] first document whose first token is at or after the tile's
 };
 int64_t dec_tile_ids();
 void launch_dec_mark(const DecArgs& d, hipStream_t s);

@@ -654,12 +654,14 @@ void build_decode_tables(const std::unordered_map<std::string, int32_t>& vocab, 
         const std::string& k = *key[id];
         if (decode_alone(k, 0, out)) T.dec_flag[id] |= DEC_F_CONTEXT;
         if (out.size() >= DEC_NOSTRIP) continue;  // cannot happen with 2047-byte keys; stays DEC_BAD
+        T.dec_blob.resize((T.dec_blob.size() + 3) & ~(size_t)3, 0);  // entries start on 4-byte boundaries
         T.dec_off[id] = (uint32_t)T.dec_blob.size();
         T.dec_len[id] = (uint16_t)out.size();
         T.dec_blob.insert(T.dec_blob.end(), out.begin(), out.end());
         if (!pfx.empty()) {
             if (k.size() >= pfx.size() && k.compare(0, pfx.size(), pfx) == 0) {
                 if (decode_alone(k, pfx.size(), out)) T.dec_flag[id] |= DEC_F_CONTEXT;
+                T.dec_blob.resize((T.dec_blob.size() + 3) & ~(size_t)3, 0);
                 T.dec_soff[id] = (uint32_t)T.dec_blob.size();
                 T.dec_slen[id] = (uint16_t)out.size();
                 T.dec_blob.insert(T.dec_blob.end(), out.begin(), out.end());
@@ -668,7 +670,7 @@ void build_decode_tables(const std::unordered_map<std::string, int32_t>& vocab, 
             }
         }
     }
-    T.dec_blob.resize(T.dec_blob.size() + 16, 0);  // 16-byte reads at a token's offset stay inside
+    T.dec_blob.resize(((T.dec_blob.size() + 3) & ~(size_t)3) + 16, 0);  // 16-byte reads at a token's offset stay inside
 }
 
 }  // namespace
