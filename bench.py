@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--cpu-docs", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code "
+                         "path where RCCL cannot run, e.g. two ranks sharing one GPU with HUTK_BENCH_DEVICE=0)")
     ap.add_argument("--merges", action="store_true",
                     help="secondary configuration: the id-keyed merge path (VG with its merges file, SURVEY 8 f-1); "
                          "the default and BASELINE metric is the string-keyed path")
@@ -114,16 +117,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hutoken_amd encode path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("HUTK_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from hutoken_amd import _capi, data as hdata, synth
     vp, sp, kw = hdata.vocab_files("VG")
     mp = hdata.merges_file("VG") if args.merges else None
-    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=local_rank, merges_path=mp)
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=dev_index, merges_path=mp)
 
     n_docs = args.docs or synth.KINDS[args.corpus][2]
     cores = os.cpu_count() or 1
@@ -139,8 +147,8 @@ def main():
     d_ids = torch.empty(cap, dtype=torch.int32, device=dev)
     d_oo = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
     d_err = torch.zeros(1, dtype=torch.int32, device=dev)
-    d_tot = torch.zeros(1, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    d_tot = torch.zeros(1, dtype=torch.int64, device=cdev)
+    gathered = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
@@ -169,10 +177,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tb = torch.tensor([n_bytes], dtype=torch.int64, device=dev)
+        tb = torch.tensor([n_bytes], dtype=torch.int64, device=cdev)
         dist.all_reduce(tb)
         total_bytes = int(tb.item())
     else:
