@@ -87,8 +87,9 @@ struct hutk_ctx {
     DevBuf<uint2> d_dec_ent, d_dec_sent;
     DevBuf<uint8_t> d_dec_blob;
     DecTables dec{};
-    DevBuf<uint32_t> dw_first, dw_count;
-    DevBuf<int64_t> dw_base, dw_tfd;
+    DevBuf<uint32_t> dw_first;
+    DevBuf<unsigned long long> dw_state;
+    DevBuf<int64_t> dw_tfd;
     DevBuf<int32_t> ds_ids, ds_status;
     DevBuf<int64_t> ds_offs, ds_oo;
     DevBuf<uint8_t> ds_bytes;
@@ -218,13 +219,26 @@ int upload_tables(hutk_ctx* c) {
     {
         const size_t N = (size_t)T.dec_n;
         std::vector<uint2> ent(N ? N : 1), sent;
-        for (size_t i = 0; i < N; i++) ent[i] = make_uint2(T.dec_off[i], (uint32_t)T.dec_len[i] | ((uint32_t)T.dec_flag[i] << 16));
+        auto pack = [&](uint32_t off, uint32_t len, bool bad) {
+            if (bad) return make_uint2(DEC_TAG_BAD, 0u);
+            if (len > DEC_INLINE_MAX) return make_uint2(DEC_TAG_LONG | (len << 8), off);
+            uint64_t v = len;
+            for (uint32_t j = 0; j < len; j++) v |= (uint64_t)T.dec_blob[off + j] << (8 * (j + 1));
+            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        };
+        // DEC_F_PFX_PARTIAL only matters at the front of a document
+        for (size_t i = 0; i < N; i++)
+            ent[i] = pack(T.dec_off[i], T.dec_len[i], T.dec_len[i] == DEC_BAD || (T.dec_flag[i] & ~DEC_F_PFX_PARTIAL));
         HIP_TRY(c->d_dec_ent.reserve(ent.size()));
         HIP_TRY(hipMemcpy(c->d_dec_ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice));
         c->dec.sent = nullptr;
         if (!T.dec_slen.empty()) {
             sent.resize(N ? N : 1);
-            for (size_t i = 0; i < N; i++) sent[i] = make_uint2(T.dec_soff[i], (uint32_t)T.dec_slen[i]);
+            for (size_t i = 0; i < N; i++) {
+                const bool strip = T.dec_slen[i] != DEC_NOSTRIP;
+                const uint32_t len = strip ? T.dec_slen[i] : T.dec_len[i];
+                sent[i] = pack(strip ? T.dec_soff[i] : T.dec_off[i], len, len == DEC_BAD || T.dec_flag[i]);
+            }
             HIP_TRY(c->d_dec_sent.reserve(sent.size()));
             HIP_TRY(hipMemcpy(c->d_dec_sent.p, sent.data(), sent.size() * sizeof(uint2), hipMemcpyHostToDevice));
             c->dec.sent = c->d_dec_sent.p;
@@ -303,7 +317,7 @@ void destroy(hutk_ctx* c) {
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
         c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
-        c->dw_count.release(); c->dw_base.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
+        c->dw_state.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
         c->ds_offs.release(); c->ds_oo.release(); c->ds_bytes.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release();
@@ -639,8 +653,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     const int64_t n_tiles = (n_ids + tile - 1) / tile;
     if (n_tiles > 0x7FFFFFFFll) return set_err(HUTK_E_ARG, "batch too large");
     HIP_TRY(c->dw_first.reserve((size_t)(n_ids / 32 + 4)));
-    HIP_TRY(c->dw_count.reserve((size_t)n_tiles + 8));
-    HIP_TRY(c->dw_base.reserve((size_t)n_tiles + n_tiles / 2048 + 16));
+    HIP_TRY(c->dw_state.reserve((size_t)n_tiles + 8));
     HIP_TRY(c->dw_tfd.reserve((size_t)n_tiles + 1));
     HIP_TRY(c->w_err.reserve(1));
     DecArgs D{};
@@ -655,8 +668,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     D.status = d_status;
     D.err = d_err ? d_err : c->w_err.p;
     D.first_bits = c->dw_first.p;
-    D.tile_count = c->dw_count.p;
-    D.tile_base = c->dw_base.p;
+    D.tile_state = c->dw_state.p;
     D.tile_first_doc = c->dw_tfd.p;
     HIP_TRY(hipMemsetAsync(D.err, 0, 4, s));
     const bool strip = c->dec.sent != nullptr;  // the first-token bitmap is only needed to strip a prefix
@@ -668,17 +680,8 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
         return HUTK_OK;
     }
     if (strip) launch_dec_mark(D, s);
-    launch_dec_sizes(c->dec, D, s);
-    {  // exclusive scan of the tile byte counts with the encode direction's scan kernels
-        BatchArgs A{};
-        A.n_tiles = n_tiles;
-        Workspace W{};
-        W.tile_count = D.tile_count;
-        W.tile_base = D.tile_base;
-        W.scan_part = c->dw_base.p + n_tiles + 2;
-        launch_scan(A, W, s);
-    }
-    launch_dec_write(c->dec, D, s);
+    HIP_TRY(hipMemsetAsync(D.tile_state, 0, (size_t)n_tiles * 8, s));
+    launch_dec(c->dec, D, s);
     HIP_TRY(hipGetLastError());
     return HUTK_OK;
 }

@@ -8,9 +8,10 @@
 // segmented gather: lengths -> exclusive scan -> copy.  HBM-bound: 4 bytes read per id, the text written once.
 //
 //   k_dec_mark    first-token bitmap of the documents (prefix stripping, document offsets)
-//   k_dec_tiles   <false>: bytes per tile of DEC_TILE ids; <true>: after the scan of the tile totals (the
-//                 k_scan_* kernels of the encode direction), stage the tile's text in LDS, store it in
-//                 16-byte chunks, write out_offsets of the documents that start in the tile
+//   k_dec_pre     first document per tile of DEC_TILE ids
+//   k_dec_tiles   ONE pass: lengths of the tile's tokens, block scan, the tile's offset in the text by
+//                 decoupled look-back over the earlier tiles' totals, the text staged in LDS and stored in
+//                 16-byte chunks, out_offsets of the documents that start in the tile
 //   k_dec_tail    out_offsets of the (empty) documents at the very end
 #include <hip/hip_runtime.h>
 
@@ -62,60 +63,57 @@ __device__ __forceinline__ uint32_t dec_wave_incl(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
+constexpr unsigned long long DEC_ST_MASK = 3ull << 62, DEC_ST_TOTAL = 1ull << 62, DEC_ST_PREFIX = 2ull << 62;
 constexpr int DEC_LDS_BYTES = 24 * 1024;  // text of one tile staged for coalesced stores (mean ~8 KB)
 
-// token i of the batch: (offset into the blob, output length); errors are reported here
+// token i of the batch: its table entry (see DecTables); errors are reported here and leave an empty token
 __device__ __forceinline__ uint2 dec_entry(const DecTables& T, const DecArgs& D, int64_t i, int32_t id, bool first) {
     if (id < 0 || (int64_t)id >= T.n) {
         dec_raise(D.err, HUTK_E_VALUE);  // "Element must be non-negative and less than vocab size."
         if (D.status) D.status[dec_doc_of(D, i)] = HUTK_DOC_ID_OUT_OF_RANGE;
         return make_uint2(0, 0);
     }
-    uint2 e = T.ent[id];  // x: offset, y: length | flags << 16
-    uint32_t flags = e.y >> 16;
-    uint32_t len = e.y & 0xFFFFu;
-    if (first && T.sent) {  // first token of its document and a prefix is configured
-        const uint2 s = T.sent[id];
-        if ((s.y & 0xFFFFu) != DEC_NOSTRIP_DEV) {
-            e.x = s.x;
-            len = s.y & 0xFFFFu;
-        }
-    } else {
-        flags &= ~(uint32_t)DEC_FD_PFX_PARTIAL;  // only matters at the front of a document
-    }
-    if (len == DEC_BAD_DEV || flags) {
+    const uint2 e = (first && T.sent) ? T.sent[id] : T.ent[id];
+    if ((e.x & 0xFFu) == DEC_TAG_BAD) {
         dec_raise(D.err, HUTK_E_UNSUPPORTED);
         if (D.status) D.status[dec_doc_of(D, i)] = HUTK_DOC_ID_UNDECODABLE;
         return make_uint2(0, 0);
     }
-    return make_uint2(e.x, len);
+    return e;
 }
+__device__ __forceinline__ uint32_t dec_len_of(uint2 e) { return (e.x & DEC_TAG_LONG) ? e.x >> 8 : (e.x & 0xFFu); }
 
 template <bool WRITE>
 __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs D) {
     __shared__ uint32_t s_part[DEC_THREADS / 64];
-    __shared__ uint16_t s_pref[WRITE ? DEC_TILE : 2];  // bytes of the tile before each of its tokens
-    __shared__ __attribute__((aligned(16))) uint8_t s_text[WRITE ? DEC_LDS_BYTES : 16];
+    __shared__ uint16_t s_pref[DEC_TILE];  // bytes of the tile before each of its tokens
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[WRITE ? DEC_LDS_BYTES + 16 : 16];
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * DEC_TILE + (int64_t)tid * DEC_PER_THREAD;
-    uint32_t off[DEC_PER_THREAD], len[DEC_PER_THREAD];
+    uint2 ent[DEC_PER_THREAD];
+    uint32_t len[DEC_PER_THREAD];
     uint32_t firsts = 0;  // bit k: token i0 + k starts a document
     {
         const uint32_t w = (D.first_bits && i0 < D.n_ids) ? D.first_bits[i0 >> 5] : 0u;  // DEC_PER_THREAD = 8 divides 32
         firsts = (w >> (i0 & 31)) & 0xFFu;
     }
-    uint32_t mine = 0;
+    int32_t id[DEC_PER_THREAD];
+    if (i0 + DEC_PER_THREAD <= D.n_ids && (reinterpret_cast<uintptr_t>(D.ids) & 15) == 0) {  // two 16-byte loads
+        const int4 a = *reinterpret_cast<const int4*>(D.ids + i0), b = *reinterpret_cast<const int4*>(D.ids + i0 + 4);
+        id[0] = a.x; id[1] = a.y; id[2] = a.z; id[3] = a.w;
+        id[4] = b.x; id[5] = b.y; id[6] = b.z; id[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < DEC_PER_THREAD; k++) id[k] = (i0 + k < D.n_ids) ? D.ids[i0 + k] : 0;
+    }
+    uint32_t mine = 0, any_long = 0;
 #pragma unroll
     for (int k = 0; k < DEC_PER_THREAD; k++) {
-        const int64_t i = i0 + k;
-        off[k] = 0;
-        len[k] = 0;
-        if (i < D.n_ids) {
-            const uint2 e = dec_entry(T, D, i, D.ids[i], (firsts >> k) & 1u);
-            off[k] = e.x;
-            len[k] = e.y;
-        }
+        ent[k] = make_uint2(0, 0);
+        if (i0 + k < D.n_ids) ent[k] = dec_entry(T, D, i0 + k, id[k], (firsts >> k) & 1u);
+        len[k] = dec_len_of(ent[k]);
+        any_long |= ent[k].x & DEC_TAG_LONG;
         mine += len[k];
     }
     // block exclusive scan of the per-thread byte counts: DPP scan per wavefront, then the four wave totals
@@ -130,13 +128,18 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
         total += t;
     }
     uint32_t before = wave_base + incl - mine;
-    if (!WRITE) {
-        if (tid == 0) D.tile_count[tile] = total;
-        return;
-    }
-    const int64_t g0 = D.tile_base[tile];  // byte offset of the tile's text in the output
-    // bytes before each token of the tile, then out_offsets of the documents whose first token is in the tile
-    // (consecutive documents from tile_first_doc on, empty ones included; coalesced reads of id_offsets)
+    // Byte offset of the tile's text = total of all earlier tiles, by decoupled look-back: every tile
+    // publishes its own total at once and its inclusive prefix as soon as it knows it; a tile adds up the totals
+    // of its predecessors back to the nearest published prefix (workgroups are dispatched in index order, so
+    // every predecessor is running or done).  One pass over the ids instead of sizes + scan + write.
+    // Flag and value share one 64-bit word, so relaxed agent-scope atomics suffice: nothing else is
+    // communicated, and acquire/release at agent scope would write back / invalidate the XCD's L2 per tile.
+    unsigned long long* st = D.tile_state;
+    if (tid == 0 && tile > 0)
+        __hip_atomic_store(&st[tile], DEC_ST_TOTAL | (unsigned long long)total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    // While the predecessors get there: bytes before each token of the tile, and the tile's text staged in LDS
+    // from index 0 (its alignment in the output is not known yet).
     {
         uint32_t pos = before;
 #pragma unroll
@@ -145,7 +148,70 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
             pos += len[k];
         }
     }
+    const bool write = WRITE && D.bytes_out != nullptr;
+    const bool staged = write && total <= (uint32_t)DEC_LDS_BYTES;  // (always < 65536: s_pref holds 16-bit positions)
+    if (staged) {
+        // short tokens (almost all) carry their bytes in the entry; long ones are copied from the blob
+        // (OR-ing shifted dwords into a zeroed area with LDS atomics instead of byte stores: measured 5 % slower)
+        uint32_t pos = before;
+#pragma unroll
+        for (int k = 0; k < DEC_PER_THREAD; k++) {
+            const uint64_t bits = (((uint64_t)ent[k].y << 32) | ent[k].x) >> 8;
+            const uint32_t n_in = (ent[k].x & DEC_TAG_LONG) ? 0u : len[k];
+#pragma unroll
+            for (int j = 0; j < (int)DEC_INLINE_MAX; j++)
+                if ((uint32_t)j < n_in) s_text[pos + j] = (uint8_t)(bits >> (8 * j));
+            pos += len[k];
+        }
+        if (any_long) {
+            pos = before;
+#pragma unroll
+            for (int k = 0; k < DEC_PER_THREAD; k++) {
+                if (ent[k].x & DEC_TAG_LONG) {
+                    const uint8_t* src = T.blob + ent[k].y;
+                    for (uint32_t j = 0; j < len[k]; j++) s_text[pos + j] = src[j];
+                }
+                pos += len[k];
+            }
+        }
+    }
+    __shared__ int64_t s_g0;
+    if (tid < 64) {  // wavefront 0 looks back
+        const int lane = tid;
+        int64_t excl = 0;
+        if (tile > 0) {
+            for (int64_t hi = tile - 1;; hi -= 64) {  // predecessors hi, hi-1, ... hi-63, one per lane
+                const int64_t p = hi - lane;
+                unsigned long long v = DEC_ST_PREFIX;  // lanes before tile 0: an empty prefix
+                if (p >= 0) {
+                    uint32_t spins = 0;
+                    do {
+                        v = __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > (1u << 22)) {  // seconds: the dispatch-order premise does not hold;
+                            dec_raise(D.err, HUTK_E_DEVICE);  // fail loudly instead of hanging the GPU
+                            v = DEC_ST_PREFIX;
+                        }
+                    } while ((v & DEC_ST_MASK) == 0);
+                }
+                const unsigned long long has_prefix = __ballot((v & DEC_ST_MASK) == DEC_ST_PREFIX);
+                // lanes up to and including the nearest one with a prefix contribute
+                const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 63;
+                int64_t part = (lane <= stop) ? (int64_t)(v & ~DEC_ST_MASK) : 0;
+                for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o, 64);
+                excl += part;
+                if (has_prefix) break;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&st[tile], DEC_ST_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            s_g0 = excl;
+        }
+    }
     __syncthreads();
+    const int64_t g0 = s_g0;  // byte offset of the tile's text in the output
+    // out_offsets of the documents whose first token is in the tile (consecutive documents from tile_first_doc
+    // on, empty ones included; coalesced reads of id_offsets)
     {
         const int64_t t0 = tile * DEC_TILE, t1 = t0 + DEC_TILE;
         for (int64_t d = D.tile_first_doc[tile] + tid; d < D.n_docs; d += DEC_THREADS) {
@@ -154,51 +220,44 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
             D.out_offsets[d] = g0 + s_pref[i - t0];
         }
     }
-    if (!D.bytes_out) return;
+    if (!write) return;
     if (g0 + (int64_t)total > D.bytes_cap) {
         if (tid == 0) dec_raise(D.err, HUTK_E_CAPACITY);
         return;
     }
-    const uint32_t shift = (uint32_t)(g0 & 15);  // LDS index and global address agree modulo 16
-    if (total + shift <= (uint32_t)DEC_LDS_BYTES) {  // (always < 65536: s_pref holds 16-bit positions)
-        // the first 16 bytes of all eight tokens are loaded before any is used (entries are 4-byte aligned and
-        // the blob has 16 bytes of slack): one round trip per thread, not one per byte
-        uint4 v[DEC_PER_THREAD];
-#pragma unroll
-        for (int k = 0; k < DEC_PER_THREAD; k++)
-            v[k] = len[k] ? *reinterpret_cast<const uint4*>(T.blob + off[k]) : make_uint4(0, 0, 0, 0);
-        uint32_t pos = before + shift;
-#pragma unroll
-        for (int k = 0; k < DEC_PER_THREAD; k++) {
-            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if ((uint32_t)j < len[k]) s_text[pos + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-            if (len[k] > 8) {
-#pragma unroll
-                for (int j = 8; j < 16; j++)
-                    if ((uint32_t)j < len[k]) s_text[pos + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
-                const uint8_t* src = T.blob + off[k];
-                for (uint32_t j = 16; j < len[k]; j++) s_text[pos + j] = src[j];
-            }
-            pos += len[k];
-        }
-        __syncthreads();
+    if (staged) {
+        // 16-byte aligned stores: chunk c of the output holds text bytes [c - shift, c - shift + 16), read from
+        // LDS as five dwords and realigned
+        const uint32_t shift = (uint32_t)(g0 & 15);
         uint8_t* gbase = D.bytes_out + (g0 - shift);  // 16-byte aligned
         const uint32_t end = total + shift;
+        const uint32_t* text32 = reinterpret_cast<const uint32_t*>(s_text);
         for (uint32_t c = (uint32_t)tid * 16; c < end; c += DEC_THREADS * 16) {
             if (c >= shift && c + 16 <= end) {
-                *reinterpret_cast<uint4*>(gbase + c) = *reinterpret_cast<const uint4*>(s_text + c);
+                const uint32_t t = c - shift, r = t & 3u;
+                const uint32_t* q = text32 + (t >> 2);
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+                uint4 o;
+                o.x = __builtin_amdgcn_alignbyte(w1, w0, r);
+                o.y = __builtin_amdgcn_alignbyte(w2, w1, r);
+                o.z = __builtin_amdgcn_alignbyte(w3, w2, r);
+                o.w = __builtin_amdgcn_alignbyte(w4, w3, r);
+                *reinterpret_cast<uint4*>(gbase + c) = o;
             } else {  // first and last chunk: only the bytes that belong to this tile
-                for (uint32_t j = (c < shift ? shift : c); j < c + 16 && j < end; j++) gbase[j] = s_text[j];
+                for (uint32_t j = (c < shift ? shift : c); j < c + 16 && j < end; j++) gbase[j] = s_text[j - shift];
             }
         }
     } else {  // a tile of unusually long tokens: straight to memory
         uint8_t* dst = D.bytes_out + g0 + before;
 #pragma unroll
         for (int k = 0; k < DEC_PER_THREAD; k++) {
-            const uint8_t* src = T.blob + off[k];
-            for (uint32_t j = 0; j < len[k]; j++) dst[j] = src[j];
+            if (ent[k].x & DEC_TAG_LONG) {
+                const uint8_t* src = T.blob + ent[k].y;
+                for (uint32_t j = 0; j < len[k]; j++) dst[j] = src[j];
+            } else {
+                const uint64_t bits = (((uint64_t)ent[k].y << 32) | ent[k].x) >> 8;
+                for (uint32_t j = 0; j < len[k]; j++) dst[j] = (uint8_t)(bits >> (8 * j));
+            }
             dst += len[k];
         }
     }
@@ -209,7 +268,8 @@ __global__ void k_dec_tail(DecArgs D) {
     if (d > D.n_docs) return;
     // documents without a first token of their own (empty ones) that are not followed by a non-empty one
     // inside the batch, and the end marker: everything decoded so far = the grand total
-    if (d == D.n_docs || D.id_offsets[d] >= D.n_ids) D.out_offsets[d] = D.tile_base[D.n_tiles];
+    if (d == D.n_docs || D.id_offsets[d] >= D.n_ids)
+        D.out_offsets[d] = (int64_t)(D.tile_state[D.n_tiles - 1] & ~DEC_ST_MASK);  // inclusive prefix of the last tile
 }
 
 int64_t dec_tile_ids() { return DEC_TILE; }
@@ -217,12 +277,10 @@ int64_t dec_tile_ids() { return DEC_TILE; }
 void launch_dec_mark(const DecArgs& d, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_mark, dim3((unsigned)((d.n_docs + 255) / 256)), dim3(256), 0, s, d);
 }
-void launch_dec_sizes(const DecTables& t, const DecArgs& d, hipStream_t s) {
+void launch_dec(const DecTables& t, const DecArgs& d, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_pre, dim3((unsigned)((d.n_tiles + 255) / 256)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(k_dec_tiles<false>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
-}
-void launch_dec_write(const DecTables& t, const DecArgs& d, hipStream_t s) {
-    hipLaunchKernelGGL(k_dec_tiles<true>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
+    if (d.bytes_out) hipLaunchKernelGGL(k_dec_tiles<true>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
+    else hipLaunchKernelGGL(k_dec_tiles<false>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
     hipLaunchKernelGGL(k_dec_tail, dim3((unsigned)((d.n_docs + 1 + 255) / 256)), dim3(256), 0, s, d);
 }
 

@@ -108,10 +108,13 @@ struct BatchArgs {
 };
 
 // ---- decode direction (hutk_decode.hip) ----
-constexpr uint32_t DEC_BAD_DEV = 0xFFFFu, DEC_NOSTRIP_DEV = 0xFFFEu, DEC_FD_PFX_PARTIAL = 8u;
+// One 8-byte entry per id.  Low byte of x = tag: 0..7 the token's output is that many bytes, held in the
+// entry itself (bytes 1..7); DEC_TAG_LONG: x >> 8 = length, y = offset into the blob; DEC_TAG_BAD: the token
+// cannot be decoded on its own (no key, several keys, or context dependent).
+constexpr uint32_t DEC_TAG_LONG = 0x80u, DEC_TAG_BAD = 0xFFu, DEC_INLINE_MAX = 7u;
 struct DecTables {
-    const uint2* ent;     // [n] x: offset into blob, y: output length (DEC_BAD_DEV: cannot be decoded) | flags << 16
-    const uint2* sent;    // [n] the same with the prefix stripped from the token's front, or null (no prefix)
+    const uint2* ent;     // [n] entry of a token that is not the first of its document
+    const uint2* sent;    // [n] entry of a document's first token (prefix stripped), or null (no prefix: use ent)
     const uint8_t* blob;  // output bytes
     int64_t n;            // ids 0..n-1 are in range (number of vocabulary lines, lib.c:377)
 };
@@ -125,14 +128,12 @@ struct DecArgs {
     int32_t* status;            // may be null
     int32_t* err;
     uint32_t* first_bits;       // [n_ids / 32 + 2] bit i: token i is the first of a document
-    uint32_t* tile_count;       // [n_tiles] bytes per tile of ids
-    int64_t* tile_base;         // [n_tiles + 1] their exclusive scan
+    unsigned long long* tile_state;  // [n_tiles] decoupled look-back: flag (2 bits) | total or inclusive prefix
     int64_t* tile_first_doc;    // [n_tiles] first document whose first token is at or after the tile's
 };
 int64_t dec_tile_ids();
 void launch_dec_mark(const DecArgs& d, hipStream_t s);
-void launch_dec_sizes(const DecTables& t, const DecArgs& d, hipStream_t s);
-void launch_dec_write(const DecTables& t, const DecArgs& d, hipStream_t s);
+void launch_dec(const DecTables& t, const DecArgs& d, hipStream_t s);
 
 // hutk_kernels.hip
 void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);

@@ -49,4 +49,4 @@ print(json.dumps({"metric": "GB/s of text decoded (GPT-2-shaped vocab), bit-exac
                   "config": {"workload": f"C3 {args.docs} docs, {len(d)/1e6:.1f} MB of text, {n_ids} ids, device-resident"},
                   "roofline": {"bound": "hbm", "achieved": round(b_alg / dt / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(b_alg / dt / 8e12, 4), "algorithmic_bytes": b_alg,
-                               "note": "whole decode pipeline (5 launches), not one kernel"}}))
+                               "note": "whole decode pipeline (memset, k_dec_pre, k_dec_tiles, k_dec_tail), dominated by k_dec_tiles"}}))
