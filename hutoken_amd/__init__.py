@@ -66,9 +66,8 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
 
 
 def initialize(model_or_path, *args, **kwargs):
-    """hutoken.initialize (reference hutoken.py:22-120).  Local vocabulary files
-    only: the Hugging Face branch needs the network and `transformers` to fetch a
-    tokenizer and is not part of this path.
+    """hutoken.initialize (reference hutoken.py:22-120): local vocabulary files, or a Hugging Face
+    model id / directory that `transformers` can resolve offline (see hutoken_amd/hf.py).
 
     Merges file: the reference's local-file branch checks that args[6] exists and then
     drops it (hutoken.py:30-43 never hands it to _hutoken.initialize); only its Hugging
@@ -92,8 +91,21 @@ def initialize(model_or_path, *args, **kwargs):
             raise ValueError(f"The provided merges file '{merges_kw}' does not exist.")
         return _native_initialize(model_or_path, special_chars_file, prefix, is_byte_encoder, token_id,
                                   regex_pattern, merges_kw, device=device)
-    raise ValueError("Could not download Hugging Face tokenizer "
-                     f"'{model_or_path}': hutoken_amd loads local vocabulary files only")
+    # Hugging Face branch (hutoken.py:44-120): convert the tokenizer to huToken's files, then the same native
+    # initialisation, on the id-keyed merge path when the tokenizer has merge rules
+    from . import hf
+    ex = hf.export(model_or_path, **kwargs)
+    try:
+        kw = {k: v for k, v in kwargs.items() if k not in ("is_byte_encoder",)}
+        kw.setdefault("device", int(os.environ.get("HUTOKEN_DEVICE", "-1")))
+        if "token_id" in kw:
+            kw["special_token_id"] = kw.pop("token_id")
+        return _native_initialize(ex["vocab_file"], ex["special_chars_file"], ex["prefix"], ex["is_byte_encoder"],
+                                  *args, merges_file_path=ex["merges_file_path"], **kw)
+    except Exception as e:
+        traceback.print_exc(file=sys.stderr)
+        raise RuntimeError("An unexpected error occured during "
+                           f"initialization: {e}") from e
 
 
 def _pack(texts):
