@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include "hutk_classify.h"
 #include "hutk_device.h"
 
 using namespace hutk;
@@ -65,7 +66,7 @@ struct hutk_ctx {
     DevBuf<uint64_t> d_pair, d_char;
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
     DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
-    DevBuf<uint8_t> d_item_direct;
+    DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<uint4> d_word_keys, d_word_short;
     DevBuf<uint32_t> d_word_syms;
@@ -161,6 +162,13 @@ int upload_tables(hutk_ctx* c) {
     D.sym_id = c->d_sym_id.p;
     D.n_vocab_sym = T.n_vocab_sym;
     D.n_sym = T.n_sym;
+    {  // splitter automaton: transition table + byte classes, independent of the vocabulary
+        std::vector<uint8_t> buf(dfa::TABLE_BYTES + 256);
+        dfa::build(reinterpret_cast<uint16_t*>(buf.data()), buf.data() + dfa::TABLE_BYTES);
+        HIP_TRY(c->d_split_dfa.reserve(buf.size()));
+        HIP_TRY(hipMemcpy(c->d_split_dfa.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
+        D.split_dfa = reinterpret_cast<const uint4*>(c->d_split_dfa.p);
+    }
     D.item_sym = c->d_item_sym.p;
     D.item_direct = c->d_item_direct.p;
     D.char_slots = c->d_char.p;
@@ -310,7 +318,7 @@ void destroy(hutk_ctx* c) {
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
-        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();

@@ -1,12 +1,15 @@
 // hutk_classify.h -- the reference's word splitter (src/parser.c:24-183) restated
-// for 16 consecutive positions at a time, in two forms:
+// for 16 consecutive positions at a time, in three forms:
 //
-//   classify16        byte-parallel (SWAR) mask algebra, ~500 integer ops per 16 bytes
-//   classify16_exact  per-position decode; handles the overlong encodings the SWAR
-//                     form defers (it reports them through *exotic)
+//   classify16_dfa    a 31-state automaton over byte classes, one table lookup per byte (the form k_tiles
+//                     uses: ~160 integer instructions + 46 LDS reads per 16 positions)
+//   classify16        byte-parallel (SWAR) mask algebra, ~650 integer ops per 16 positions (k_tiles with
+//                     -DHUTK_SPLIT_SWAR=1; kept as the independent second implementation the fuzz compares)
+//   classify16_exact  per-position decode; handles the overlong encodings the other two
+//                     defer (they report them through *exotic)
 //
 // Compiled for the device (k_tiles) AND for the host (tests/cpu/classify_check.cpp
-// fuzzes both against the oracle's sequential splitter), so it is plain integer C++.
+// fuzzes all three against the oracle's sequential splitter), so it is plain integer C++.
 //
 // Input: a 32-byte window d[0..7] (little-endian dwords; window byte k is the text
 // byte at position p0 - 8 + k, zero outside the data) and `dbits`, bit k set when a
@@ -274,6 +277,177 @@ HUTK_CLS_HD uint32_t classify16(const uint32_t (&d)[8], uint32_t dbits, bool* ex
         flags |= movemask4(start) << (4 * (i - 2));
     }
     return flags;
+}
+
+// ---------------------------------------------------------------------------
+// table-driven form: the splitter as a finite automaton over (byte class, "a document starts here").
+//
+// The mask algebra above spends ~800 instructions per 16 positions; the same function is a 31-state
+// automaton, and a lane that walks it over window bytes 4..26 needs one LDS lookup and three integer
+// instructions per byte.  State = what the next start decision depends on:
+//   no character pending: class of the previous character -- A, D, O, lone space (a space after a non-space
+//     or at a document start: the "[ ]?" of the next word), further space, or W/X (each its own word);
+//   inside a multi-byte character: how many bytes are still due, which lead it was (C3 / C5 followers decide
+//     between Hungarian letter and class O; E0 / F0 followers decide overlong or not), and the start flag the
+//     character will get when it completes as class A / class O (that is all the earlier context it needs).
+// A start is known when a character completes, up to three bytes after its lead, so a transition emits four
+// flags: bit j <-> the byte 3 - j before the current one.  A sequence that breaks (a byte that is no
+// continuation, or a document start) turns every byte consumed so far into a one-byte word (class X).
+// Overlong forms (C0/C1 leads, E0 + 80..9F, F0 + 80..8F) end in an absorbing EXOTIC state: the caller falls
+// back to classify16_exact, as with the mask algebra.
+//
+// Exactness for positions 0..15 from a cold start at window byte 4: continuation bytes at the front of the
+// window are taken as stray although a lead before the window may own them; that can only change flags
+// before position 0, because the first byte that is not a continuation (window byte 7 at the latest)
+// resynchronises the character structure, and the character in front of position 0 then starts inside the
+// window.  Whether a space at window byte 4 is lone needs window byte 3, which picks the initial state.
+// ---------------------------------------------------------------------------
+namespace dfa {
+enum : int {
+    C_ALPHA, C_DIGIT, C_SPACE, C_WS, C_NUL, C_OTHER,                    // bytes < 0x80
+    C_80, C_80_H3, C_90, C_90_H3, C_90_H5, C_A0, C_A0_H3, C_A0_H5,       // continuation bytes; H3 / H5: Hungarian
+    C_L_C0C1, C_L_C3, C_L_C5, C_L_2, C_L_E0, C_L_3, C_L_F0, C_L_4, C_L_BAD,  // letter after a C3 / C5 lead
+    N_CLS
+};
+enum : int { S_A, S_D, S_O, S_SL, S_SM, S_WX, S_P2 = 6, S_PC3 = 8, S_PC5 = 12, S_P3 = 16, S_EXOTIC = 30, N_STATES = 31 };
+enum : int { P3a, PE0, P3b, P4a, PF0, P4b, P4c };  // pending three- and four-byte characters: S_P3 + 2 * p + flag
+constexpr int ROW_BYTES = 128;                     // one row per state: 2 * N_CLS 16-bit entries, padded
+constexpr int DOC_COL_BYTES = 2 * N_CLS;           // the columns for "a document starts at this byte"
+constexpr int TABLE_BYTES = N_STATES * ROW_BYTES;
+static_assert(2 * DOC_COL_BYTES <= ROW_BYTES, "row holds both column sets");
+
+inline int byte_class(uint32_t b) {
+    if (b < 0x80u) {
+        switch (cls_ascii(b)) {
+            case K_ALPHA: return C_ALPHA;
+            case K_DIGIT: return C_DIGIT;
+            case K_SPACE: return C_SPACE;
+            case K_WS: return C_WS;
+            case K_BAD: return C_NUL;
+            default: return C_OTHER;
+        }
+    }
+    if (b < 0xC0u) {
+        const bool h3 = (HUN_AFTER_C3 >> (b - 0x80u)) & 1ull, h5 = (HUN_AFTER_C5 >> (b - 0x80u)) & 1ull;
+        if (b < 0x90u) return h3 ? C_80_H3 : C_80;
+        if (b < 0xA0u) return h3 ? C_90_H3 : h5 ? C_90_H5 : C_90;
+        return h3 ? C_A0_H3 : h5 ? C_A0_H5 : C_A0;
+    }
+    if (b < 0xC2u) return C_L_C0C1;
+    if (b == 0xC3u) return C_L_C3;
+    if (b == 0xC5u) return C_L_C5;
+    if (b < 0xE0u) return C_L_2;
+    if (b == 0xE0u) return C_L_E0;
+    if (b < 0xF0u) return C_L_3;
+    if (b == 0xF0u) return C_L_F0;
+    if (b < 0xF8u) return C_L_4;
+    return C_L_BAD;
+}
+
+// start flag of a character of class A / D / O (cls = S_A / S_D / S_O) after context ctx (parser.c:24-58)
+inline bool start_after(int ctx, int cls) { return !(ctx == cls || ctx == S_SL); }
+
+struct Step { int next; unsigned emit; };
+
+// no character pending, context ctx, byte of class c; ds: a document starts at this byte
+inline Step fresh(int ctx, int c, bool ds) {
+    const unsigned HERE = 8u;  // emission bit of the current byte
+    const bool sp = ctx == S_SL || ctx == S_SM;
+    switch (c) {
+        case C_ALPHA: return {S_A, (ds || start_after(ctx, S_A)) ? HERE : 0u};
+        case C_DIGIT: return {S_D, (ds || start_after(ctx, S_D)) ? HERE : 0u};
+        case C_OTHER: return {S_O, (ds || start_after(ctx, S_O)) ? HERE : 0u};
+        case C_SPACE: return {(ds || !sp) ? S_SL : S_SM, (ds || !sp) ? HERE : 0u};
+        case C_L_C0C1: return {S_EXOTIC, 0u};
+        case C_L_C3: case C_L_C5: case C_L_2: case C_L_E0: case C_L_3: case C_L_F0: case C_L_4: {
+            const int cx = ds ? S_WX : ctx;  // a document start forces the start whatever the class turns out to be
+            const int fa = start_after(cx, S_A), fo = start_after(cx, S_O);
+            switch (c) {
+                case C_L_C3: return {S_PC3 + 2 * fa + fo, 0u};
+                case C_L_C5: return {S_PC5 + 2 * fa + fo, 0u};
+                case C_L_2: return {S_P2 + fo, 0u};
+                case C_L_E0: return {S_P3 + 2 * PE0 + fo, 0u};
+                case C_L_3: return {S_P3 + 2 * P3a + fo, 0u};
+                case C_L_F0: return {S_P3 + 2 * PF0 + fo, 0u};
+                default: return {S_P3 + 2 * P4a + fo, 0u};
+            }
+        }
+        default: return {S_WX, HERE};  // \t\n\v\f\r, 0x00, a stray continuation byte, F8..FF: one-byte words
+    }
+}
+
+inline Step step(int st, int c, bool ds) {
+    if (st == S_EXOTIC) return {S_EXOTIC, 0u};
+    if (st <= S_WX) return fresh(st, c, ds);
+    // a character is pending: which one, with which flags, and how many of its bytes are behind us
+    int prog = -1, fa = 0, fo = 0, consumed = 1;
+    if (st < S_PC3) { fo = st - S_P2; }
+    else if (st < S_PC5) { fa = (st - S_PC3) >> 1; fo = (st - S_PC3) & 1; }
+    else if (st < S_P3) { fa = (st - S_PC5) >> 1; fo = (st - S_PC5) & 1; }
+    else {
+        prog = (st - S_P3) >> 1;
+        fo = (st - S_P3) & 1;
+        consumed = (prog == P3b || prog == P4b) ? 2 : (prog == P4c) ? 3 : 1;
+    }
+    const bool cont = c >= C_80 && c <= C_A0_H5;
+    if (ds || !cont) {  // broken: the bytes consumed so far are one-byte words, then this byte on its own
+        const unsigned flush = ((1u << consumed) - 1u) << (3 - consumed);
+        const Step f = fresh(S_WX, c, ds);
+        return {f.next, f.next == S_EXOTIC ? 0u : (flush | f.emit)};
+    }
+    if (st < S_PC3) return {S_O, fo ? 4u : 0u};
+    if (st < S_PC5) {
+        const bool hun = c == C_80_H3 || c == C_90_H3 || c == C_A0_H3;
+        return {hun ? S_A : S_O, (hun ? fa : fo) ? 4u : 0u};
+    }
+    if (st < S_P3) {
+        const bool hun = c == C_90_H5 || c == C_A0_H5;
+        return {hun ? S_A : S_O, (hun ? fa : fo) ? 4u : 0u};
+    }
+    switch (prog) {
+        case P3a: return {S_P3 + 2 * P3b + fo, 0u};
+        case PE0: return {c >= C_A0 ? S_P3 + 2 * P3b + fo : S_EXOTIC, 0u};  // E0 80..9F: overlong
+        case P3b: return {S_O, fo ? 2u : 0u};
+        case P4a: return {S_P3 + 2 * P4b + fo, 0u};
+        case PF0: return {c >= C_90 ? S_P3 + 2 * P4b + fo : S_EXOTIC, 0u};  // F0 80..8F: overlong
+        case P4b: return {S_P3 + 2 * P4c + fo, 0u};
+        default: return {S_O, fo ? 1u : 0u};
+    }
+}
+
+// table[TABLE_BYTES / 2] and lut[256] for classify16_dfa (built once on the host, staged in LDS by k_tiles)
+inline void build(uint16_t* table, uint8_t* lut) {
+    for (int b = 0; b < 256; b++) lut[b] = (uint8_t)(2 * byte_class((uint32_t)b));
+    for (int st = 0; st < N_STATES; st++)
+        for (int col = 0; col < ROW_BYTES / 2; col++) {
+            Step r{S_EXOTIC, 0u};
+            if (col < 2 * N_CLS) r = step(st, col % N_CLS, col >= N_CLS);
+            table[st * (ROW_BYTES / 2) + col] = (uint16_t)((r.next * ROW_BYTES) | r.emit);
+        }
+}
+}  // namespace dfa
+
+HUTK_CLS_HD uint32_t classify16_dfa(const uint32_t (&d)[8], uint32_t dbits, const uint16_t* table, const uint8_t* lut,
+                                    bool* exotic) {
+    // column offsets of window bytes 4..26 first: these lookups do not depend on the state
+    uint32_t col[23];
+    HUTK_CLS_UNROLL
+    for (int k = 4; k <= 26; k++) {
+        const uint32_t b = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        col[k - 4] = lut[b] + ((dbits >> k) & 1u) * (uint32_t)dfa::DOC_COL_BYTES;
+    }
+    // (two walks side by side, the second starting cold at window byte 12, were no faster: measured)
+    uint32_t st = ((d[0] >> 24) == 0x20u ? dfa::S_SM : dfa::S_WX) * dfa::ROW_BYTES;
+    uint32_t acc = 0;  // bit i <-> window byte i + 1
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(table);
+    HUTK_CLS_UNROLL
+    for (int k = 4; k <= 26; k++) {
+        const uint32_t e = *reinterpret_cast<const uint16_t*>(t8 + (st | col[k - 4]));
+        acc |= (e & 15u) << (k - 4);
+        st = e & 0xFF80u;
+    }
+    *exotic = st == (uint32_t)(dfa::S_EXOTIC * dfa::ROW_BYTES);
+    return (acc >> 7) & 0xFFFFu;
 }
 
 }  // namespace hutk

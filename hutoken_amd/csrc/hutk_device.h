@@ -57,6 +57,9 @@ struct DevTables {
     const uint4* word_keys;
     const uint32_t* word_syms;
     uint32_t wordl_mask;
+    // the word splitter as an automaton (hutk_classify.h, namespace dfa): dfa::TABLE_BYTES of transition table, then
+    // the 256-byte byte-class table; the same for every vocabulary, staged in LDS by k_tiles
+    const uint4* split_dfa;
 };
 
 // one word the tile kernel hands to the exception kernel

@@ -5,12 +5,14 @@
 //
 //   k_pre      per tile: first document that can touch the tile (binary search)
 //   k_tiles    THE hot kernel.  One wavefront per tile of 960 input bytes, TILE_WAVES tiles per
-//              workgroup in byte-encoder mode (1 otherwise):
+//              workgroup:
 //                1. coalesced 16-byte loads of the bytes (+16 before, +80 after) into LDS,
-//                   document-start bitmap of the window
-//                2. each lane classifies its 16 positions IN REGISTERS from a 32-byte
-//                   window (the reference's splitter, src/parser.c:24-183, is a function
-//                   of a +-5 byte neighbourhood) and emits 16 word-start bits
+//                   document-start bitmap of the window; the workgroup's copy of the splitter's
+//                   transition table (4 KB, in the LDS the merge phase uses later)
+//                2. each lane classifies its 16 positions from a 32-byte register window (the
+//                   reference's splitter, src/parser.c:24-183, is a function of a +-5 byte
+//                   neighbourhood) by walking a 31-state automaton, one LDS lookup per byte
+//                   (hutk_classify.h), and emits 16 word-start bits
 //                3. words go to the lanes round-robin; one round = one memory round trip:
 //                   whole-word table probe (raw bytes -> the single token of the word),
 //                   first-byte symbol, unit count; outcome: one symbol / needs merging /
@@ -290,7 +292,6 @@ struct TileLds {
     __attribute__((aligned(8))) uint32_t livem[NPOS / 32 + 2];   // surviving units (see phase 5)
     uint16_t stage[64];  // word starts handed to the lanes, 64 at a time; the epilogue's lane prefix later
     __attribute__((aligned(16))) SymT S[NPOS];  // symbol of unit i of the word at ws: S[ws + i]
-    __attribute__((aligned(16))) SymT M[NPOS];  // merge loop: pair result of units (i, next live) at M[ws + i]
     // non-byte mode with a prefix: the first word of a document gets the prefix units in front of its own,
     // which does not fit its byte span; up to ARENA_WORDS such words per tile keep their units in this side
     // arena (more than that: exception path)
@@ -302,16 +303,28 @@ struct TileLds {
 };
 
 template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? 6 : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? 7 : 6) : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
     constexpr int POOL_CAP = 128 * WAVES, POOL_LONG_CAP = 48 * WAVES, POOL_LONG = 8;
     static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
     __shared__ Tile L[WAVES];
-    __shared__ uint16_t pool[POOL_CAP];
-    __shared__ uint32_t pool_cnt[2];
+    __shared__ uint32_t pool[POOL_CAP];
+    __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of s_m.m handed out
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
+    // merge loop: pair result of units (i, next live) of a pooled word at m[its offset + i]; a word gets its
+    // stretch of m when it enters the pool (a position-indexed array per tile would be four times the size, and
+    // LDS is what limits the resident wavefronts).  The merge phase begins behind a workgroup barrier that every
+    // wavefront passes after its classification, so until then the same LDS holds the transition table of the
+    // splitter automaton (hutk_classify.h); the byte classes are beside it.
+    constexpr int M_ARENA = 2048;
+    static_assert(M_ARENA * sizeof(SymT) >= (size_t)dfa::TABLE_BYTES && M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
+    __shared__ __attribute__((aligned(16))) union {
+        SymT m[M_ARENA];
+        uint8_t dfa[dfa::TABLE_BYTES];
+    } s_m;
+    __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
@@ -371,13 +384,18 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
     const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
+    for (int i = threadIdx.x; i < (dfa::TABLE_BYTES + 256) / 16; i += 64 * WAVES) {
+        const uint4 v = T.split_dfa[i];
+        if (i < dfa::TABLE_BYTES / 16) reinterpret_cast<uint4*>(s_m.dfa)[i] = v;
+        else reinterpret_cast<uint4*>(s_lut)[i - dfa::TABLE_BYTES / 16] = v;
+    }
     if (!BYTE_MODE) {
         for (int i = threadIdx.x; i < 256; i += 64 * WAVES) {
             s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
             s_item_direct[i] = T.item_direct[i];
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (tile_ok) {
         HUTK_STAMP(0);
 
@@ -424,7 +442,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
             bool exotic;
+#if HUTK_SPLIT_SWAR
             flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
+#else
+            flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.dfa), s_lut,
+                                   &exotic);                   // the automaton: one LDS lookup per byte
+#endif
             if (exotic) {  // overlong encodings: per-position decode
                 Win8 w8;
     #pragma unroll
@@ -624,10 +647,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     // ones first, and the short rest finishes in a few trips.  The instruction stream is what bounds this
     // kernel, so that is worth three workgroup barriers.
     //   pool[0 .. n_long)              words with more than POOL_LONG units
-    //   pool[POOL_CAP-1 downto ...]    the others; an entry is (tile-in-workgroup << 10) | word start
+    //   pool[POOL_CAP-1 downto ...]    the others; an entry is offset in m << 16 | tile-in-workgroup << 10 | word start
     // Words that do not fit stay in their tile's mergem and go into the next epoch (rare).
     for (;;) {
-        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; }
+        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
         __syncthreads();
         uint32_t pending = 0;
         if (tile_ok) {
@@ -637,9 +660,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const int ws = 16 * lane + j;
                 const int n = word_units(me, ws);
                 const bool is_long = n > POOL_LONG;
+                const uint32_t moff = atomicAdd(&pool_cnt[2], (uint32_t)n);
+                if (moff + n > (uint32_t)M_ARENA) continue;  // no room in m this epoch
                 const uint32_t idx = atomicAdd(&pool_cnt[is_long ? 0 : 1], 1u);
                 if (idx < (uint32_t)(is_long ? POOL_LONG_CAP : POOL_CAP - POOL_LONG_CAP)) {
-                    pool[is_long ? idx : POOL_CAP - 1 - idx] = (uint16_t)((wv << 10) | ws);
+                    pool[is_long ? idx : POOL_CAP - 1 - idx] = (moff << 16) | (uint32_t)((wv << 10) | ws);
                     pending &= ~(1u << j);
                 }
             }
@@ -652,10 +677,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             const uint32_t wi = base + lane;
             bool have = wi < n_pool;
             const uint32_t entry = have ? (wi < n_long ? pool[wi] : pool[POOL_CAP - 1 - (wi - n_long)]) : 0u;
-            Tile& X = L[entry >> 10];  // the word's tile
+            Tile& X = L[(entry >> 10) & 63u];  // the word's tile
             const int ws = entry & 1023;
             SymT* Sw = X.S + ws;
-            SymT* Mw = X.M + ws;
+            SymT* Mw = s_m.m + (entry >> 16);
             int arena_slot = -1;
             int n = 0;
             if (have) {
@@ -1824,8 +1849,9 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_pre, dim3(g), dim3(256), 0, s, a, w);
 }
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    // byte-encoder mode pools the merge-loop words of TILE_WAVES tiles; the character mode has few words in
-    // the merge loop (its whole-word table covers most of them) and keeps one tile per workgroup
+    // TILE_WAVES tiles per workgroup: they pool their merge-loop words and share one copy of the splitter's
+    // transition table in LDS (one tile per workgroup outside byte-encoder mode was 17 % slower once the table
+    // was there: fewer resident wavefronts)
 #define HUTK_LAUNCH(ST, BM, RS, WV)                                                                     \
     hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)((a.n_tiles + WV - 1) / WV)), dim3(64 * WV), 0, s, \
                        t, a, w)
@@ -1833,12 +1859,12 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     switch (variant) {
         case 7: HUTK_LAUNCH(uint16_t, true, true, TILE_WAVES); break;
         case 6: HUTK_LAUNCH(uint16_t, true, false, TILE_WAVES); break;
-        case 5: HUTK_LAUNCH(uint16_t, false, true, 1); break;
-        case 4: HUTK_LAUNCH(uint16_t, false, false, 1); break;
+        case 5: HUTK_LAUNCH(uint16_t, false, true, TILE_WAVES); break;
+        case 4: HUTK_LAUNCH(uint16_t, false, false, TILE_WAVES); break;
         case 3: HUTK_LAUNCH(uint32_t, true, true, TILE_WAVES); break;
         case 2: HUTK_LAUNCH(uint32_t, true, false, TILE_WAVES); break;
-        case 1: HUTK_LAUNCH(uint32_t, false, true, 1); break;
-        default: HUTK_LAUNCH(uint32_t, false, false, 1); break;
+        case 1: HUTK_LAUNCH(uint32_t, false, true, TILE_WAVES); break;
+        default: HUTK_LAUNCH(uint32_t, false, false, TILE_WAVES); break;
     }
 #undef HUTK_LAUNCH
 }

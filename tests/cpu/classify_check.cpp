@@ -32,7 +32,7 @@ static const char* PIECES[] = {
 int main(int argc, char** argv) {
     const long n_cases = argc > 1 ? atol(argv[1]) : 20000;
     rng_s = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1;
-    const int mode = argc > 3 ? atoi(argv[3]) : 0;  // 1: no overlong pieces (keeps the SWAR path in play)
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;  // 1: no overlong pieces (keeps the fast paths in play); 2: byte soup
     const int NP = (int)(sizeof(PIECES) / sizeof(PIECES[0]));
     auto overlong = [](const char* pc) {
         const unsigned char* u = (const unsigned char*)pc;
@@ -40,16 +40,26 @@ int main(int argc, char** argv) {
             if (*u == 0xC0 || *u == 0xC1 || (*u == 0xE0 && u[1] < 0xA0) || (*u == 0xF0 && u[1] < 0x90)) return true;
         return false;
     };
-    long bad = 0, exotic_windows = 0, windows = 0;
+    long bad = 0, exotic_windows = 0, windows = 0, dfa_exotic = 0;
+    static uint16_t dfa_table[hutk::dfa::TABLE_BYTES / 2];
+    static uint8_t dfa_lut[256];
+    hutk::dfa::build(dfa_table, dfa_lut);
     for (long cs = 0; cs < n_cases; cs++) {
         // a batch of a few documents packed back to back
         std::vector<uint8_t> text;
         std::vector<size_t> offs{0};
         const int n_docs = 1 + (int)(rnd() % 4);
         for (int dd = 0; dd < n_docs; dd++) {
-            const int np = (int)(rnd() % 14);
+            const int np = (int)(rnd() % (mode == 2 ? 40 : 14));
             const bool ascii_only = rnd() % 4 == 0;
             for (int i = 0; i < np; i++) {
+                if (mode == 2) {  // single bytes: leads, continuation bytes and ASCII in any order (no overlong leads)
+                    static const uint8_t B[] = {' ', ' ', 'a', 'b', '1', '.', '\n', 0xC2, 0xC3, 0xC3, 0xC5, 0xC5, 0xD0, 0xE1, 0xE2,
+                                                0xED, 0xF1, 0xF4, 0xF7, 0xF8, 0x80, 0x81, 0x90, 0x91, 0x96, 0xA0, 0xA1, 0xA9,
+                                                0xB0, 0xB1, 0xBF, 0x9C, 0xBC, 0x8D};
+                    text.push_back(B[rnd() % sizeof(B)]);
+                    continue;
+                }
                 const char* pc = PIECES[rnd() % (ascii_only ? 22 : NP)];
                 if (mode == 1 && overlong(pc)) { i--; continue; }
                 text.insert(text.end(), pc, pc + strlen(pc));
@@ -77,15 +87,18 @@ int main(int argc, char** argv) {
             bool exotic = false;
             const uint32_t fs = hutk::classify16(d, dbits, &exotic);
             const uint32_t fe = hutk::classify16_exact(d, dbits);
+            bool exotic_d = false;
+            const uint32_t fd = hutk::classify16_dfa(d, dbits, dfa_table, dfa_lut, &exotic_d);
+            dfa_exotic += exotic_d;
             windows++;
             exotic_windows += exotic;
             for (int j = 0; j < 16 && p0 + j < n; j++) {
                 const uint32_t want = expect[p0 + j];
-                const uint32_t got_e = (fe >> j) & 1u, got_s = (fs >> j) & 1u;
-                if (got_e != want || (!exotic && got_s != want)) {
+                const uint32_t got_e = (fe >> j) & 1u, got_s = (fs >> j) & 1u, got_d = (fd >> j) & 1u;
+                if (got_e != want || (!exotic && got_s != want) || (!exotic_d && got_d != want)) {
                     if (bad < 10) {
-                        fprintf(stderr, "MISMATCH case %ld pos %zu: want %u exact %u swar %u exotic %d  text:", cs,
-                                p0 + j, want, got_e, got_s, (int)exotic);
+                        fprintf(stderr, "MISMATCH case %ld pos %zu: want %u exact %u swar %u exotic %d dfa %u exotic %d  text:",
+                                cs, p0 + j, want, got_e, got_s, (int)exotic, got_d, (int)exotic_d);
                         for (size_t q = 0; q < n; q++) fprintf(stderr, " %02x%s", text[q], docstart[q + 1] ? " |" : "");
                         fprintf(stderr, "\n");
                     }
@@ -94,6 +107,7 @@ int main(int argc, char** argv) {
             }
         }
     }
-    printf("cases %ld windows %ld exotic %ld mismatches %ld\n", n_cases, windows, exotic_windows, bad);
+    printf("cases %ld windows %ld exotic %ld dfa-exotic %ld mismatches %ld\n", n_cases, windows, exotic_windows,
+           dfa_exotic, bad);
     return bad ? 1 : 0;
 }

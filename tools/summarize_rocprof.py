@@ -53,7 +53,7 @@ if trace:
         durs = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in k]
         lines += [f"k_tiles durations (us), last {min(10, len(durs))}: " + ", ".join(f"{d:.1f}" for d in durs[-10:]), ""]
 
-lines += ["## PMC counters (per k_tiles dispatch, mean over the run's dispatches)", ""]
+lines += ["## PMC counters (per full-size k_tiles dispatch, mean over the run's dispatches of the bench workload)", ""]
 pmc = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -61,8 +61,11 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
         lines.append(f"- {os.path.basename(d)}: no counter file (set rejected?)")
         continue
     acc = defaultdict(list)
-    for r in csv.DictReader(open(files[0])):
-        if "k_tiles" in r.get("Kernel_Name", ""):
+    rows = [r for r in csv.DictReader(open(files[0])) if "k_tiles" in r.get("Kernel_Name", "")]
+    # only the full-size launches of the bench workload (context creation runs a small one to verify its tables)
+    full = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for r in rows:
+        if int(r["Grid_Size"]) == full:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for name, vals in acc.items():
         lines.append(f"- {name}: {sum(vals) / len(vals):.4g}  (n={len(vals)})")
