@@ -247,6 +247,9 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // No workgroup barriers: a long word delays only its own wavefront.
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
+#ifndef HUTK_WAVES_EU
+#define HUTK_WAVES_EU 8
+#endif
 constexpr int TILE_WAVES = 4;  // tiles (= wavefronts) per workgroup of k_tiles
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
@@ -303,28 +306,38 @@ struct TileLds {
 };
 
 template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? 7 : 6) : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
-    constexpr int POOL_CAP = 128 * WAVES, POOL_LONG_CAP = 48 * WAVES, POOL_LONG = 8;
+#ifndef HUTK_LDS_TIGHT
+#define HUTK_LDS_TIGHT 1
+#endif
+    constexpr int POOL_CAP = (HUTK_LDS_TIGHT ? 64 : 128) * WAVES, POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
     static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
     __shared__ Tile L[WAVES];
-    __shared__ uint32_t pool[POOL_CAP];
-    __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of s_m.m handed out
+    __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
-    // merge loop: pair result of units (i, next live) of a pooled word at m[its offset + i]; a word gets its
-    // stretch of m when it enters the pool (a position-indexed array per tile would be four times the size, and
-    // LDS is what limits the resident wavefronts).  The merge phase begins behind a workgroup barrier that every
-    // wavefront passes after its classification, so until then the same LDS holds the transition table of the
-    // splitter automaton (hutk_classify.h); the byte classes are beside it.
-    constexpr int M_ARENA = 2048;
-    static_assert(M_ARENA * sizeof(SymT) >= (size_t)dfa::TABLE_BYTES && M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
-    __shared__ __attribute__((aligned(16))) union {
+    // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
+    // m[its offset + i]; a word gets its stretch of m when it enters the pool (a position-indexed array per tile
+    // would be four times the size, and LDS is what limits the resident wavefronts).  The merge phase begins
+    // behind a workgroup barrier that every wavefront passes after its classification, so until then the same
+    // LDS holds the splitter automaton (hutk_classify.h): transition table, then byte classes.
+    constexpr int M_ARENA = HUTK_LDS_TIGHT ? 1600 : 2048;
+    struct MergeLds {
         SymT m[M_ARENA];
+        uint32_t pool[POOL_CAP];
+    };
+    struct SplitLds {
         uint8_t dfa[dfa::TABLE_BYTES];
+        uint8_t lut[256];
+    };
+    static_assert(M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
+    __shared__ __attribute__((aligned(16))) union {
+        MergeLds g;
+        SplitLds c;
     } s_m;
-    __shared__ __attribute__((aligned(16))) uint8_t s_lut[256];
+    uint32_t* const pool = s_m.g.pool;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
@@ -386,8 +399,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
     for (int i = threadIdx.x; i < (dfa::TABLE_BYTES + 256) / 16; i += 64 * WAVES) {
         const uint4 v = T.split_dfa[i];
-        if (i < dfa::TABLE_BYTES / 16) reinterpret_cast<uint4*>(s_m.dfa)[i] = v;
-        else reinterpret_cast<uint4*>(s_lut)[i - dfa::TABLE_BYTES / 16] = v;
+        reinterpret_cast<uint4*>(&s_m.c)[i] = v;  // table, then byte classes, as uploaded
     }
     if (!BYTE_MODE) {
         for (int i = threadIdx.x; i < 256; i += 64 * WAVES) {
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_SPLIT_SWAR
             flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
 #else
-            flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.dfa), s_lut,
+            flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.c.dfa), s_m.c.lut,
                                    &exotic);                   // the automaton: one LDS lookup per byte
 #endif
             if (exotic) {  // overlong encodings: per-position decode
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             Tile& X = L[(entry >> 10) & 63u];  // the word's tile
             const int ws = entry & 1023;
             SymT* Sw = X.S + ws;
-            SymT* Mw = s_m.m + (entry >> 16);
+            SymT* Mw = s_m.g.m + (entry >> 16);
             int arena_slot = -1;
             int n = 0;
             if (have) {
