@@ -250,7 +250,10 @@ constexpr int N_PHASE = 10;
 #ifndef HUTK_WAVES_EU
 #define HUTK_WAVES_EU 8
 #endif
-constexpr int TILE_WAVES = 4;  // tiles (= wavefronts) per workgroup of k_tiles
+#ifndef HUTK_TILE_WAVES
+#define HUTK_TILE_WAVES 4
+#endif
+constexpr int TILE_WAVES = HUTK_TILE_WAVES;  // tiles (= wavefronts) per workgroup of k_tiles
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
 
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     // would be four times the size, and LDS is what limits the resident wavefronts).  The merge phase begins
     // behind a workgroup barrier that every wavefront passes after its classification, so until then the same
     // LDS holds the splitter automaton (hutk_classify.h): transition table, then byte classes.
-    constexpr int M_ARENA = HUTK_LDS_TIGHT ? 1600 : 2048;
+    constexpr int M_ARENA = HUTK_LDS_TIGHT ? 352 * WAVES + 192 : 2048;
     struct MergeLds {
         SymT m[M_ARENA];
         uint32_t pool[POOL_CAP];
@@ -661,6 +664,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     //   pool[0 .. n_long)              words with more than POOL_LONG units
     //   pool[POOL_CAP-1 downto ...]    the others; an entry is offset in m << 16 | tile-in-workgroup << 10 | word start
     // Words that do not fit stay in their tile's mergem and go into the next epoch (rare).
+#if HUTK_ABLATE_MERGE
+    if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
+#endif
     for (;;) {
         if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
         __syncthreads();
