@@ -247,6 +247,9 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // No workgroup barriers: a long word delays only its own wavefront.
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
+#ifndef HUTK_CHAR_EU
+#define HUTK_CHAR_EU 6
+#endif
 #ifndef HUTK_WAVES_EU
 #define HUTK_WAVES_EU 8
 #endif
@@ -309,7 +312,7 @@ struct TileLds {
 };
 
 template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : 5) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
 #ifndef HUTK_LDS_TIGHT
