@@ -346,7 +346,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     uint32_t* const pool = s_m.g.pool;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b works on
+    // tile group (b % 8) * (groups / 8) + b / 8, so every XCD walks one contiguous eighth of the batch and the
+    // lines two neighbouring tiles share (halo, lookback, offsets) meet in one L2.  The grid is a multiple of 8.
+    const int64_t wg = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t tile = wg * WAVES + wv;
     const bool tile_ok = tile < A.n_tiles;  // a wavefront without a tile still merges pooled words
     Tile& me = L[wv];
     uint8_t* const sb = me.sb;
@@ -1874,7 +1878,7 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     // transition table in LDS (one tile per workgroup outside byte-encoder mode was 17 % slower once the table
     // was there: fewer resident wavefronts)
 #define HUTK_LAUNCH(ST, BM, RS, WV)                                                                     \
-    hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)((a.n_tiles + WV - 1) / WV)), dim3(64 * WV), 0, s, \
+    hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), dim3(64 * WV), 0, s, \
                        t, a, w)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
     switch (variant) {
