@@ -52,9 +52,10 @@ if trace:
         lines += ["## k_tiles dispatch", "", ", ".join(f"{x}={r[x]}" for x in keys), ""]
         durs = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in k]
         lines += [f"k_tiles durations (us), last {min(10, len(durs))}: " + ", ".join(f"{d:.1f}" for d in durs[-10:]), ""]
-        if "Grid_Size" in r:
-            full = max(int(x["Grid_Size"]) for x in k)
-            fd = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in k if int(x["Grid_Size"]) == full]
+        gs = "Grid_Size" if "Grid_Size" in r else "Grid_Size_X" if "Grid_Size_X" in r else None
+        if gs:
+            full = max(int(x[gs]) for x in k)
+            fd = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in k if int(x[gs]) == full]
             lines += [f"mean over the {len(fd)} full-size launches of the bench workload: {sum(fd) / len(fd):.1f} us "
                       f"(the --stats average above also counts the {len(k) - len(fd)} small launch(es) with which context "
                       "creation verifies its tables)", ""]
