@@ -244,7 +244,16 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // ------------------------------------------------------------------------
 // k_tiles: ONE WAVEFRONT per tile of 960 input bytes (+64 bytes of halo in which a
 // word that starts in the tile may end).  Lane l owns positions 16l .. 16l+15.
-// No workgroup barriers: a long word delays only its own wavefront.
+// Workgroup barriers only around the pooled merge phase.
+//
+// Build switches (defaults are what ships; the others exist for A/B runs with tools/ab.py and for the
+// measurements quoted in DESIGN.md section 5):
+//   HUTK_TILE_WAVES   tiles per workgroup (4; 8 and 16 measured no faster)
+//   HUTK_WAVES_EU     resident wavefronts per SIMD the byte-mode kernel is compiled for (8 = 64 VGPRs)
+//   HUTK_CHAR_EU      the same outside byte-encoder mode (6: LDS-limited)
+//   HUTK_LDS_TIGHT    1: pool and merge array sized so that 8 workgroups fit a CU's LDS; 0: roomier (7)
+//   HUTK_SPLIT_SWAR   1: classify with the SWAR mask algebra instead of the automaton
+//   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
 #ifndef HUTK_CHAR_EU
