@@ -38,7 +38,11 @@ __device__ __forceinline__ int64_t dec_doc_of(const DecArgs& D, int64_t i) {
     return lo;
 }
 
-constexpr int DEC_THREADS = 256, DEC_PER_THREAD = 8, DEC_TILE = DEC_THREADS * DEC_PER_THREAD;
+#ifndef HUTK_DEC_PER_THREAD
+#define HUTK_DEC_PER_THREAD 8
+#endif
+constexpr int DEC_THREADS = 256, DEC_PER_THREAD = HUTK_DEC_PER_THREAD, DEC_TILE = DEC_THREADS * DEC_PER_THREAD;
+static_assert(DEC_PER_THREAD % 4 == 0 && 32 % DEC_PER_THREAD == 0, "16-byte id loads; a thread's first-token bits sit in one word");
 
 // first document whose first token is at or after the tile's first token (binary search, once per tile)
 __global__ void k_dec_pre(DecArgs D) {
@@ -65,7 +69,7 @@ __device__ __forceinline__ uint32_t dec_wave_incl(uint32_t v) {
 }
 constexpr unsigned long long DEC_ST_MASK = 3ull << 62, DEC_ST_TOTAL = 1ull << 62, DEC_ST_PREFIX = 2ull << 62;
 constexpr int DEC_LOOK = 1;  // look-back window = 64 * DEC_LOOK tiles per round trip (4: measured 9 % slower)
-constexpr int DEC_LDS_BYTES = 24 * 1024;  // text of one tile staged for coalesced stores (mean ~8 KB)
+constexpr int DEC_LDS_BYTES = 3 * 1024 * DEC_PER_THREAD;  // text of one tile staged for coalesced stores (mean a third of it)
 
 // token i of the batch: its table entry (see DecTables); errors are reported here and leave an empty token
 __device__ __forceinline__ uint2 dec_entry(const DecTables& T, const DecArgs& D, int64_t i, int32_t id, bool first) {
@@ -97,13 +101,15 @@ __global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs 
     uint32_t firsts = 0;  // bit k: token i0 + k starts a document
     {
         const uint32_t w = (D.first_bits && i0 < D.n_ids) ? D.first_bits[i0 >> 5] : 0u;  // DEC_PER_THREAD = 8 divides 32
-        firsts = (w >> (i0 & 31)) & 0xFFu;
+        firsts = (w >> (i0 & 31)) & ((1u << DEC_PER_THREAD) - 1u);
     }
     int32_t id[DEC_PER_THREAD];
     if (i0 + DEC_PER_THREAD <= D.n_ids && (reinterpret_cast<uintptr_t>(D.ids) & 15) == 0) {  // two 16-byte loads
-        const int4 a = *reinterpret_cast<const int4*>(D.ids + i0), b = *reinterpret_cast<const int4*>(D.ids + i0 + 4);
-        id[0] = a.x; id[1] = a.y; id[2] = a.z; id[3] = a.w;
-        id[4] = b.x; id[5] = b.y; id[6] = b.z; id[7] = b.w;
+#pragma unroll
+        for (int g = 0; g < DEC_PER_THREAD; g += 4) {
+            const int4 a = *reinterpret_cast<const int4*>(D.ids + i0 + g);
+            id[g] = a.x; id[g + 1] = a.y; id[g + 2] = a.z; id[g + 3] = a.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < DEC_PER_THREAD; k++) id[k] = (i0 + k < D.n_ids) ? D.ids[i0 + k] : 0;
