@@ -159,15 +159,16 @@ def test_dense_word_tiles(small_byte):
 
 
 def test_merge_pool_overflow(small_byte):
-    """More merge-loop words in a workgroup's four tiles than its pool holds (512, of which 192 long ones):
-    the rest waits in the tiles and goes through further epochs.  Words are random letter strings, so nearly
-    none is a vocabulary key and all of them need the merge loop."""
+    """More merge-loop words in a workgroup's four tiles than its pool holds (256, of which 96 long ones) or than
+    fit its merge array (1600 units): the rest waits in the tiles and goes through further epochs.  Words are
+    random letter strings, so nearly none is a vocabulary key and all of them need the merge loop."""
     rng = random.Random(23)
     def words(n_words, lo, hi):
         return b" ".join(bytes(rng.choice(b"qxzjkvwy") for _ in range(rng.randint(lo, hi))) for _ in range(n_words))
     docs = [words(3000, 2, 3),        # ~270 short merge words per tile
             words(2000, 10, 14),      # ~75 long merge words per tile
             words(1500, 2, 30),       # mixed
+            words(1500, 24, 32),      # at the lane path's unit limit: ~50 per epoch fit the merge array
             b"\n".join(words(40, 2, 20) for _ in range(60))]
     for ctx, orc in small_byte:
         _compare(ctx, orc, docs, "pool")
