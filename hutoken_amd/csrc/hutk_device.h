@@ -92,7 +92,7 @@ struct Workspace {
     uint32_t* exc_long;        // [cap_exc] records k_exc_medium left (count: counters[3]); the ends pass splits them:
     uint32_t* exc_quad;        // [cap_exc] ... words of at most 256 units for k_exc_quad (count: counters[4])
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in k_exc (count: counters[5])
-    uint32_t* counters;        // [0] exception total, [1] exception work cursor, [2] tiles with exceptions, [3] records left for k_exc
+    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)

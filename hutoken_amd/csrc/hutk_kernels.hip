@@ -895,8 +895,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     uint32_t exc_first = 0;
     if (lane == 0) {
         if (n_exc) {
-            exc_first = atomicAdd(&W.counters[0], n_exc);
-            W.exc_tiles[atomicAdd(&W.counters[2], 1u)] = (uint32_t)tile;  // k_gather_exc's work list
+            // one 64-bit atomic claims the tile's exception records (low word, counters[0]) and its place on
+            // k_gather_exc's work list (high word, counters[1]): same-address atomics are what a batch full of
+            // exception words is bound by
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(W.counters),
+                                                     (1ull << 32) | (unsigned long long)n_exc);
+            exc_first = (uint32_t)old;
+            W.exc_tiles[(uint32_t)(old >> 32)] = (uint32_t)tile;
         }
         W.tile_count[tile] = n_dense;
         W.tile_dense[tile] = n_dense;
@@ -1514,7 +1519,7 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
         if (ENDS_ONLY) {
             li = blockIdx.x + round * gridDim.x;
         } else if (round) {
-            if (lane == 0) s_idx = gridDim.x + atomicAdd(&W.counters[1], 1u);
+            if (lane == 0) s_idx = gridDim.x + atomicAdd(&W.counters[2], 1u);
             __syncthreads();
             li = s_idx;
             __syncthreads();
@@ -1806,7 +1811,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     const int tid = threadIdx.x;
-    const uint32_t n_list = W.counters[2];
+    const uint32_t n_list = W.counters[1];
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
     const int64_t tile = W.exc_tiles[li];
     const int64_t base = W.tile_base[tile];
