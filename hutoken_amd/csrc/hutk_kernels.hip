@@ -1247,27 +1247,40 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
                 }
             }
         }
-        // one merge per trip and lane: the candidate of minimal rank, leftmost on ties (queue.c:162-164)
+        // One merge per trip and lane: the candidate of minimal rank, leftmost on ties (queue.c:162-164).  As in
+        // k_tiles the lane keeps its best pair (br, bp, bm) across trips: a trip applies it, issues the lookups of
+        // the two new neighbour pairs, rescans the untouched candidates while those loads fly (four LDS reads per
+        // step), and picks the next best among {rescan, new right pair, new left pair}.
+        const bool ris = T.rank_is_sym != 0;
+        auto RKm = [&](uint32_t m) -> uint32_t { return ris ? m : ((uint32_t)T.sym_id[m] ^ 0x80000000u); };
+        auto scan4 = [&](uint64_t c, uint32_t& br, int& bp, uint32_t& bm) {
+            while (c) {
+                const uint64_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
+                const int i0 = __builtin_ctzll(c);
+                const int i1 = c1 ? __builtin_ctzll(c1) : i0, i2 = c2 ? __builtin_ctzll(c2) : i0,
+                          i3 = c3 ? __builtin_ctzll(c3) : i0;
+                const uint32_t m0 = Sym<SymT>::widen(Mm[i0 * 64 + lane]), m1 = Sym<SymT>::widen(Mm[i1 * 64 + lane]),
+                               m2 = Sym<SymT>::widen(Mm[i2 * 64 + lane]), m3 = Sym<SymT>::widen(Mm[i3 * 64 + lane]);
+                const uint32_t r0 = RKm(m0), r1 = RKm(m1), r2 = RKm(m2), r3 = RKm(m3);
+                if (r0 < br) { br = r0; bp = i0; bm = m0; }
+                if (r1 < br) { br = r1; bp = i1; bm = m1; }
+                if (r2 < br) { br = r2; bp = i2; bm = m2; }
+                if (r3 < br) { br = r3; bp = i3; bm = m3; }
+                c = c3 & (c3 - 1);
+            }
+        };
+        uint32_t br = 0xFFFFFFFFu, bm = 0;
+        int bp = 0;
+        if (have) scan4(cand, br, bp, bm);
         for (;;) {
             const bool act = have && cand != 0;
             if (!__any(act)) break;
             if (act) {
-                uint32_t br = 0xFFFFFFFFu, bm = 0;
-                int bp = 0;
-                for (uint64_t c = cand; c; c &= c - 1) {
-                    const int i = __builtin_ctzll(c);
-                    const uint32_t m = Sym<SymT>::widen(Mm[i * 64 + lane]);
-                    const uint32_t r = rank_of(T, m);
-                    if (r < br) {
-                        br = r;
-                        bp = i;
-                        bm = m;
-                    }
-                }
                 const int p = bp;
+                const uint32_t merged = bm;
                 const uint64_t above = live & ~((2ull << p) - 1ull);
                 const int q = __builtin_ctzll(above);  // the unit the merge consumes
-                Sm[p * 64 + lane] = Sym<SymT>::narrow(bm);
+                Sm[p * 64 + lane] = Sym<SymT>::narrow(merged);
                 live &= ~(1ull << q);
                 cand &= ~((1ull << q) | (1ull << p));
                 const uint64_t right = above & (above - 1ull);
@@ -1275,16 +1288,27 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
                 const int p0 = left ? 63 - __builtin_clzll(left) : 0;
                 const uint32_t sr = right ? Sym<SymT>::widen(Sm[__builtin_ctzll(right) * 64 + lane]) : 0u;
                 const uint32_t sl = left ? Sym<SymT>::widen(Sm[p0 * 64 + lane]) : 0u;
-                const PairProbe pr = pair_issue(T, bm, sr), pl = pair_issue(T, sl, bm);  // both in flight
+                const PairProbe pr = pair_issue(T, merged, sr), pl = pair_issue(T, sl, merged);  // both in flight
+                if (left) cand &= ~(1ull << p0);
+                br = 0xFFFFFFFFu;
+                scan4(cand, br, bp, bm);
                 if (right) {
-                    const uint32_t m = pair_resolve(pr, bm, sr);
+                    const uint32_t m = pair_resolve(pr, merged, sr);
                     Mm[p * 64 + lane] = Sym<SymT>::narrow(m);
-                    if (m != SYM_NONE) cand |= 1ull << p;
+                    if (m != SYM_NONE) {
+                        cand |= 1ull << p;
+                        const uint32_t r = RKm(m);
+                        if (r < br || (r == br && p < bp)) { br = r; bp = p; bm = m; }
+                    }
                 }
                 if (left) {
-                    const uint32_t m = pair_resolve(pl, sl, bm);
+                    const uint32_t m = pair_resolve(pl, sl, merged);
                     Mm[p0 * 64 + lane] = Sym<SymT>::narrow(m);
-                    if (m != SYM_NONE) cand |= 1ull << p0; else cand &= ~(1ull << p0);
+                    if (m != SYM_NONE) {
+                        cand |= 1ull << p0;
+                        const uint32_t r = RKm(m);
+                        if (r < br || (r == br && p0 < bp)) { br = r; bp = p0; bm = m; }
+                    }
                 }
             }
         }
