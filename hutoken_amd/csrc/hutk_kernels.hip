@@ -1834,6 +1834,7 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(DevTables T, Batch
 __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, BatchArgs A, Workspace W) {
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
+    __shared__ int64_t e_tok[GATHER_EXC_LDS];
     const int tid = threadIdx.x;
     const uint32_t n_list = W.counters[1];
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -1851,15 +1852,21 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
     }
     __syncthreads();  // the LDS arrays are reused from the previous tile
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
-    for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) e_pos[e] = recs[e].wpos;
+    // positions and id counts of the tile's exception words, one record per lane (all loads in flight
+    // together), then the running sum of the counts over LDS
+    for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) {
+        e_pos[e] = recs[e].wpos;
+        e_cum[e + 1] = recs[e].tok_base < 0 ? 0u : recs[e].cnt;  // (a word that was too large has no ids)
+        e_tok[e] = recs[e].tok_base;
+    }
     __syncthreads();
     if (tid == 0) {
         uint32_t acc = 0;
-        for (uint32_t e = 0; e < nexc; e++) {
+        e_cum[0] = 0;
+        for (uint32_t e = 1; e <= nexc; e++) {
+            acc += e_cum[e];
             e_cum[e] = acc;
-            acc += recs[e].cnt;
         }
-        e_cum[nexc] = acc;
     }
     __syncthreads();
     for (uint32_t k = tid; k < dense; k += GATHER_THREADS) {
@@ -1871,13 +1878,18 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
         }
         A.ids_out[base + k + e_cum[lo]] = sym_to_id(T, run_sym(k));
     }
-    for (uint32_t e = 0; e < nexc; e++) {
-        const ExcRec r = recs[e];
-        const int64_t dst = base + r.wpos + e_cum[e];
-        if (tid == 0) recs[e].out_pos = dst;
-        if (r.tok_base < 0) continue;
-        const int32_t* src = W.exc_tok + r.tok_base;
-        for (uint32_t j = tid; j < r.cnt; j += GATHER_THREADS) A.ids_out[dst + j] = src[j];
+    for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) recs[e].out_pos = base + e_pos[e] + e_cum[e];
+    // the ids of all exception words of the tile as one flat range: element k belongs to the word e with
+    // e_cum[e] <= k < e_cum[e + 1] and lands at base + wpos(e) + k; lanes are independent, so the loads of a
+    // whole stride are in flight together (one word after the other, each trip waited for its own loads)
+    const uint32_t n_flat = e_cum[nexc];
+    for (uint32_t k = tid; k < n_flat; k += GATHER_THREADS) {
+        uint32_t lo = 0, hi = nexc;  // last e with e_cum[e] <= k
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (e_cum[mid] <= k) lo = mid; else hi = mid;
+        }
+        A.ids_out[base + e_pos[lo] + k] = W.exc_tok[e_tok[lo] + (k - e_cum[lo])];
     }
     }
 }
