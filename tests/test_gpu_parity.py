@@ -110,7 +110,8 @@ def test_long_words_exception_path(small_byte):
     and beyond the LDS capacity of the exception kernel (1024 units)."""
     rng = random.Random(11)
     docs = []
-    for n in [47, 48, 49, 50, 64, 100, 191, 192, 193, 255, 256, 257, 300, 1000, 1023, 1024, 1025, 1500, 3000, 9000]:
+    for n in [47, 48, 49, 50, 62, 63, 64, 65, 100, 126, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 300, 1000, 1023, 1024,
+              1025, 1500, 3000, 9000]:
         docs.append(bytes(rng.choice(b"etaoinshr") for _ in range(n)))
         docs.append(b"pre " + bytes(rng.choice(b"etaoin") for _ in range(n)) + b" post")
         docs.append(("漢" * (n // 3 + 1)).encode("utf-8"))
