@@ -4,7 +4,9 @@ The library is built in-tree (hutoken_amd/lib/libhutoken_amd.so).  Nothing here
 computes token ids: if the library or a GPU is missing the calls raise.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 from . import build as _build
 
@@ -29,11 +31,34 @@ def library_path():
     return _build.LIB_HIP
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels carry their own copy of the HIP and HSA runtimes (torch/lib), and a process can
+    open the GPU through ONE runtime only: with /opt/rocm's loaded first by this library, a later `import
+    torch` finds "No HIP GPUs".  So when torch is installed but not yet imported, its copy is loaded here
+    (by path, without importing torch); libhutoken_amd.so then binds to it by soname, and torch to the
+    same file later.  HUTOKEN_AMD_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    if "torch" in sys.modules or os.environ.get("HUTOKEN_AMD_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load(build_if_missing=True):
     """Load libhutoken_amd.so (building it with hipcc when it is absent)."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     # HUTOKEN_AMD_LIB: another build of the same library (tools/ab.py compares two on one GPU box)
     path = os.environ.get("HUTOKEN_AMD_LIB") or _build.LIB_HIP
     if path == _build.LIB_HIP and build_if_missing and (not os.path.exists(path) or os.environ.get("HUTOKEN_AMD_REBUILD")):

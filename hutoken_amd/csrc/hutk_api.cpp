@@ -131,7 +131,8 @@ int upload_tables(hutk_ctx* c) {
     UP(c->d_sym_id, T.sym_id);
     UP(c->d_prefix_syms, T.prefix_syms);
     // byte-encoder mode: (first byte, second byte) -> {symbol of the first byte, merged symbol of the pair}
-    // in one entry, so the merge loop's set-up is one load per unit (second byte 0 = "no next unit")
+    // in one entry, so the merge loop's set-up is one load per unit (second byte 0 = "no next unit").  The index is
+    // first | second << 8: two consecutive input bytes read as one little-endian 16-bit word
     std::vector<uint32_t> bp16;
     std::vector<uint64_t> bp32;
     if (T.is_byte_encoder) {
@@ -139,12 +140,12 @@ int upload_tables(hutk_ctx* c) {
             bp16.assign(65536, 0xFFFFFFFFu);
             for (uint32_t b1 = 0; b1 < 256; b1++)
                 for (uint32_t b2 = 0; b2 < 256; b2++)
-                    bp16[(b1 << 8) | b2] = (T.item_sym[b1] & 0xFFFFu) | ((uint32_t)T.bytepair16[(b1 << 8) | b2] << 16);
+                    bp16[b1 | (b2 << 8)] = (T.item_sym[b1] & 0xFFFFu) | ((uint32_t)T.bytepair16[(b1 << 8) | b2] << 16);
         } else {
             bp32.assign(65536, ~0ull);
             for (uint32_t b1 = 0; b1 < 256; b1++)
                 for (uint32_t b2 = 0; b2 < 256; b2++)
-                    bp32[(b1 << 8) | b2] = (uint64_t)T.item_sym[b1] | ((uint64_t)T.bytepair32[(b1 << 8) | b2] << 32);
+                    bp32[b1 | (b2 << 8)] = (uint64_t)T.item_sym[b1] | ((uint64_t)T.bytepair32[(b1 << 8) | b2] << 32);
         }
     }
     UP(c->d_bytepair16, bp16);

@@ -329,6 +329,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #endif
     constexpr int POOL_CAP = (HUTK_LDS_TIGHT ? 64 : 128) * WAVES, POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
     static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
+#ifndef HUTK_FAST_MERGE
+#define HUTK_FAST_MERGE 1
+#endif
+    // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
+    constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
@@ -727,7 +732,103 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                             arena_slot = a;
                         }
             }
-            {
+            if constexpr (FAST) {
+                // Byte-encoder mode, 16-bit symbols, rank == symbol order.  A pair is the 32-bit KEY
+                // merged symbol << 5 | position: the smallest key is the pair of minimal rank, leftmost on
+                // ties (queue.c:162-164), so the best pair is one register and every comparison a v_min.
+                constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+                uint32_t live = 0, cand = 0, best = NOKEY;
+                auto scan_key = [&](uint32_t c) -> uint32_t {  // four candidates per step, their LDS reads in flight together
+                    uint32_t b = NOKEY;
+                    while (c) {
+                        const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
+                        const int i0 = __builtin_ctz(c);
+                        const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
+                                  i3 = c3 ? __builtin_ctz(c3) : i0;
+                        const uint32_t k0 = ((uint32_t)Mw[i0] << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw[i1] << 5) | (uint32_t)i1,
+                                       k2 = ((uint32_t)Mw[i2] << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw[i3] << 5) | (uint32_t)i3;
+                        b = min(min(b, k0), min(min(k1, k2), k3));
+                        c = c3 & (c3 - 1);
+                    }
+                    return b;
+                };
+                if (have) {
+                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                    // Set-up, eight units per step and no branch per unit: the word's bytes come out of LDS as three
+                    // aligned dwords; two consecutive bytes are the index of the (byte, next byte) table, whose
+                    // entry is {symbol of the byte, merged symbol of the pair}.  Units beyond the word are
+                    // looked up all the same and stored to a dummy slot.
+                    SymT* const dummy = reinterpret_cast<SymT*>(me.stage) + lane;  // the staging buffer is idle in this phase
+                    const int li = ws + LOOKBACK;
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
+                    for (int i0 = 0; i0 < n; i0 += 8) {
+                        const int a = (li + i0) & ~3, o8 = 8 * ((li + i0) & 3);
+                        const uint32_t* sw = reinterpret_cast<const uint32_t*>(X.sb + a);
+                        const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2];
+                        const uint64_t lo = (uint64_t)funnel_r(q1, q0, o8) | ((uint64_t)funnel_r(q2, q1, o8) << 32);
+                        const uint32_t k2 = q2 >> o8;  // its low byte is byte 8 of the stretch
+                        uint32_t e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t idx = j < 7 ? (uint32_t)(lo >> (8 * j)) & 0xFFFFu
+                                                       : ((uint32_t)(lo >> 56) | ((k2 & 0xFFu) << 8));
+                            e[j] = bp[idx];
+                        }
+                        uint32_t cb = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const bool in = i0 + j < n;
+                            SymT* ds = in ? Sw + i0 + j : dummy;
+                            SymT* dm = in ? Mw + i0 + j : dummy;
+                            *ds = (SymT)e[j];
+                            *dm = (SymT)(e[j] >> 16);
+                            cb |= (e[j] < 0xFFFF0000u ? 1u : 0u) << j;
+                        }
+                        cand |= cb << i0;
+                    }
+                    cand &= (1u << (n - 1)) - 1u;  // the last unit has no next one (n >= 2)
+                    best = scan_key(cand);
+                }
+                // One merge per trip: apply the best pair, ISSUE the lookups of the two new neighbour pairs, rescan the
+                // untouched candidates while those loads fly, then fold the two new keys in.
+                for (;;) {
+                    if (have && best == NOKEY) {  // done: publish the surviving units (unit 0 is in livem already)
+                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                        if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
+                        if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                        have = false;
+                    }
+                    if (!__any(have)) break;
+                    if (have) {
+                        const int p = (int)(best & 31u);
+                        const uint32_t merged = best >> 5;
+                        const uint32_t above = live & ~((2u << p) - 1u);  // not empty: bit p of cand was set
+                        const int q = __builtin_ctz(above);               // the unit the merge consumes
+                        Sw[p] = (SymT)merged;
+                        live &= ~(1u << q);
+                        const uint32_t right = above & (above - 1u);    // live units after q
+                        const uint32_t left = live & ((1u << p) - 1u);  // live units before p: none iff p == 0
+                        const int q2 = __builtin_ctz(right | 0x80000000u);
+                        const int p0 = 31 - __builtin_clz(left | 1u);   // == p when there is none
+                        const uint32_t sr = Sw[q2], sl = Sw[p0];         // (read and looked up even when absent)
+                        const PairProbe s1 = pair_issue(T, merged, sr);
+                        const PairProbe s2 = pair_issue(T, sl, merged);
+                        cand &= ~((1u << q) | (1u << p) | (1u << p0));
+                        best = scan_key(cand);
+                        uint32_t mr = pair_resolve(s1, merged, sr), ml = pair_resolve(s2, sl, merged);
+                        mr = right ? mr : SYM_NONE;
+                        ml = left ? ml : SYM_NONE;
+                        Mw[p0] = (SymT)ml;  // first: without a left neighbour p0 == p
+                        Mw[p] = (SymT)mr;
+                        const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
+                        cand |= ((hr ? 1u : 0u) << p) | ((hl ? 1u : 0u) << p0);
+                        const uint32_t kr = hr ? ((mr << 5) | (uint32_t)p) : NOKEY;
+                        const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
+                        best = min(best, min(kr, kl));
+                    }
+                }
+                wave_sync();
+            } else {
                 uint32_t live = 0, cand = 0;  // lane words have at most 32 units
                 uint32_t br = 0xFFFFFFFFu;
                 int bp = 0;
@@ -744,7 +845,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                             for (int j = 0; j < 16; j++) {  // 16 independent loads in flight
                                 const int i = i0 + j;
                                 const uint32_t b = (i < n) ? wb[i] : 0u, b2 = (i + 1 < n) ? wb[i + 1] : 0u;
-                                e[j] = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair)[(b << 8) | b2];
+                                e[j] = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair)[b | (b2 << 8)];
                             }
 #pragma unroll
                             for (int j = 0; j < 16; j++) {

@@ -11,6 +11,28 @@ from hutoken_amd import vocab_files as vf  # noqa: E402
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+BLOCK_DOCS = 100_000
+
+
+def block_hashes(ids, oo, block=BLOCK_DOCS):
+    """Per block of `block` documents: id count, sha256 of the ids (int32 LE), sha256 of the block-relative
+    offsets (int64 LE).  The unit of tests/golden/g7_full.json."""
+    import hashlib
+
+    import numpy as np
+    ids = np.asarray(ids)
+    oo = np.asarray(oo, dtype=np.int64)
+    out = []
+    n = len(oo) - 1
+    for a in range(0, n, block):
+        b = min(a + block, n)
+        seg = ids[int(oo[a]):int(oo[b])].astype("<i4", copy=False)
+        rel = (oo[a:b + 1] - oo[a]).astype("<i8", copy=False)
+        out.append({"n_ids": int(oo[b] - oo[a]), "ids_sha256": hashlib.sha256(seg.tobytes()).hexdigest(),
+                    "offsets_sha256": hashlib.sha256(rel.tobytes()).hexdigest()})
+    return out
+
+
 HU = "áéíóöőúüűÁÉÍÓÖŐÚÜŰ"
 CJK = "漢字仮名交じり文中文測試"
 EMOJI = "😂🙂🚀"

@@ -15,6 +15,10 @@ bit-for-bit) and the reference's outputs.  Run in the build container only.
       merges file whose rule order is unrelated to the ids (helpers.random_merges_text: comments,
       skipped rules, repeated pairs, CRLF), with and without a prefix, x 1500 seeded texts; VG with
       its merges file x 2000 docs of C3                       -> same
+  G7  FULL-SIZE configurations, every document: VG x all 1,000,000 docs of C3 (BASELINE config 3/4),
+      VG x all 100,000 docs of C2 (config 2), VL x all 1,000,000 docs of C5 (config 5), VG + merges x C3
+      -> per 100k-document block: id count, sha256 of the ids, sha256 of the block-relative offsets
+         (helpers.block_hashes); whole batch: id count and sha256
   G6  the DECODE direction: mid vocabularies (byte mode proper / shuffled ids, character mode with prefix)
       x 1200 id sequences each (round trips and random ids)   -> text or exception of the first 60 + sha256
 """
@@ -156,6 +160,35 @@ def g6(tmp):
     return out
 
 
+def g7():
+    """The reference over every document of the full-size configurations, 100k documents per
+    batch_encode call (8 threads); only counts and hashes are kept."""
+    out = []
+    for vocab, corpus, merges in [("VG", "C3", False), ("VG", "C2", False), ("VL", "C5", False), ("VG", "C3", True)]:
+        vp, sp, kw = data.vocab_files(vocab)
+        r = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"], data.merges_file(vocab) if merges else None)
+        n_docs = synth.KINDS[corpus][2]
+        blocks, whole, n_ids, n_bytes = [], hashlib.sha256(), 0, 0
+        csha = hashlib.sha256()
+        for first in range(0, n_docs, H.BLOCK_DOCS):
+            cnt = min(H.BLOCK_DOCS, n_docs - first)
+            d, o = synth.corpus(corpus, cnt, first_doc=first)
+            csha.update(d.tobytes())
+            n_bytes += int(o[-1])
+            res = r.batch_encode(synth.docs_as_str(d, o), 8)
+            oo = np.zeros(cnt + 1, dtype=np.int64)
+            np.cumsum(np.fromiter(map(len, res), dtype=np.int64, count=cnt), out=oo[1:])
+            ids = np.fromiter((t for x in res for t in x), dtype=np.int32, count=int(oo[-1]))
+            blocks += H.block_hashes(ids, oo)
+            whole.update(ids.astype("<i4").tobytes())
+            n_ids += len(ids)
+            print(vocab, corpus, merges, first, n_ids, flush=True)
+        out.append({"vocab": vocab, "corpus": corpus, "merges": merges, "n_docs": n_docs, "n_bytes": n_bytes,
+                    "corpus_sha256": csha.hexdigest(), "n_ids": n_ids, "sha256": whole.hexdigest(),
+                    "block_docs": H.BLOCK_DOCS, "blocks": blocks})
+    return out
+
+
 def corpus_case(tok, name, n_docs, nfirst=48):
     d, o = synth.corpus(name, n_docs)
     docs = synth.docs_as_str(d, o)
@@ -170,6 +203,9 @@ def main():
     tmp = tempfile.mkdtemp()
     if "--only-g5" in sys.argv:
         json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
+        return
+    if "--only-g7" in sys.argv:
+        json.dump(g7(), open(os.path.join(OUT, "g7_full.json"), "w"), indent=0)
         return
     if "--only-g6" in sys.argv:
         json.dump(g6(tmp), open(os.path.join(OUT, "g6_decode.json"), "w"), ensure_ascii=True)
@@ -187,6 +223,7 @@ def main():
     json.dump(g4, open(os.path.join(OUT, "g4_vl_corpora.json"), "w"))
     json.dump(g5(tmp), open(os.path.join(OUT, "g5_merges_path.json"), "w"))
     json.dump(g6(tmp), open(os.path.join(OUT, "g6_decode.json"), "w"), ensure_ascii=True)
+    json.dump(g7(), open(os.path.join(OUT, "g7_full.json"), "w"), indent=0)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
