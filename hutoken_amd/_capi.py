@@ -21,7 +21,7 @@ EXPORTS = [
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
-    "hutk_set_timing", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
+    "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
 ]
 
 _lib = None
@@ -105,6 +105,9 @@ def load(build_if_missing=True):
     L.hutk_set_timing.argtypes = [vp, i32]
     L.hutk_table_stats.restype = i32
     L.hutk_table_stats.argtypes = [vp, vp]
+    if hasattr(L, "hutk_debug_pairs_second"):  # (older builds under tools/ab.py lack it)
+        L.hutk_debug_pairs_second.restype = i64
+        L.hutk_debug_pairs_second.argtypes = [vp]
     L.hutk_debug_profile.restype = i32
     L.hutk_debug_profile.argtypes = [vp, i32]
     L.hutk_debug_tile_bytes.restype = i32

@@ -158,8 +158,8 @@ int upload_tables(hutk_ctx* c) {
     HIP_TRY(c->d_prefix_alone.reserve(EXC_LDS_UNITS));
 
     DevTables& D = c->dt;
-    D.pair_slots = reinterpret_cast<const uint2*>(c->d_pair.p);
-    D.pair_mask = T.pair_mask;
+    D.pair_buckets = reinterpret_cast<const uint4*>(c->d_pair.p);
+    D.pair_shift = T.pair_shift;
     D.sym_id = c->d_sym_id.p;
     D.n_vocab_sym = T.n_vocab_sym;
     D.n_sym = T.n_sym;
@@ -511,6 +511,7 @@ int64_t hutk_vocab_size(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_keys : 0;
 int hutk_uses_merges(const hutk_ctx* ctx) { return ctx && ctx->tab.id_path ? 1 : 0; }
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs : 0; }
 int hutk_device_ordinal(const hutk_ctx* ctx) { return ctx ? ctx->device : -1; }
+int64_t hutk_debug_pairs_second(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs_second : 0; }
 void hutk_set_timing(hutk_ctx* ctx, int enabled) {
     if (ctx) ctx->timing = enabled != 0;
 }

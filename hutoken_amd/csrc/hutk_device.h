@@ -30,8 +30,8 @@ constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units me
 enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE = 4, C_WS = 5, C_BAD = 6 };
 
 struct DevTables {
-    const uint2* pair_slots;  // x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8
-    uint32_t pair_mask;
+    const uint4* pair_buckets;  // two entries per bucket {w0, w1, w0, w1}, see hutk_internal.h
+    uint32_t pair_shift;        // bucket = hash >> pair_shift
     const int32_t* sym_id;
     uint32_t n_vocab_sym, n_sym;
     const uint32_t* item_sym;    // [256]

@@ -24,18 +24,24 @@ constexpr uint32_t SYM_UNK = (1u << SYM_BITS) - 1;  // unit that is no symbol: n
 constexpr uint32_t SYM_NONE = 0xFFFFFFFFu;          // "this pair has no rank"
 constexpr uint64_t SLOT_EMPTY = ~0ull;
 
-// pair table slot = two dwords (little-endian halves of one uint64):
-//   w0 = left | (right & 0xFFF) << 20        w1 = right >> 12 | merged << 8
-// so a probe compares 32-bit words only.  An empty slot is all ones (left = SYM_UNK
-// is never a key).
+// Pair table: BUCKETS of two 8-byte entries, one 16-byte load per lookup.  Entry (two dwords):
+//   w0 = left | (right & 0xFFF) << 20        w1 = right >> 12 | merged << 8 | filter nibble << 28
+// so a probe compares 32-bit words only.  An empty entry is w0 = all ones, w1 = 0x0FFFFFFF (left = SYM_UNK is
+// never a key; its merged field reads PAIR_ABSENT).  A pair lives in its first bucket, or -- when that was full
+// when the table was built -- in its second one; then bit (t & 7) of the first bucket's 8-bit filter (the two
+// nibbles) is set, and only lookups that miss the first bucket AND find their filter bit set go on to the
+// second (a fraction of a per cent of the lookups that find nothing).  Pairs are placed in ascending order of
+// the merged symbol, i.e. the frequent merges of a trained vocabulary get their first bucket.
+constexpr uint32_t PAIR_ABSENT = 0xFFFFFu;  // merged field of an empty entry
 static inline uint64_t pair_slot(uint32_t l, uint32_t r, uint32_t m) {
     const uint32_t w0 = l | ((r & 0xFFFu) << 20), w1 = (r >> 12) | (m << 8);
     return (uint64_t)w0 | ((uint64_t)w1 << 32);
 }
+constexpr uint64_t PAIR_EMPTY = 0x0FFFFFFFFFFFFFFFull;
 
 // The same mixing on host (table build) and device (lookup): 24-bit multiplies (full rate on CDNA) fold
-// (left, right) into one 32-bit word t; the two candidate slots are two different xor-shift views of t,
-// taken from the LOW bits.  (Two pairs with the same t share both slots, which a cuckoo table tolerates.)
+// (left, right) into one 32-bit word t.  First bucket = the top bits of t, filter bit = its low three bits,
+// second bucket (rarely computed) = the top bits of t times an odd constant, made different from the first.
 HUTK_HD uint32_t pair_mix(uint32_t l, uint32_t r) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul24(l, 0x9E3779u) ^ (__umul24(r, 0x85EBCBu) + 0x165667B1u);
@@ -44,13 +50,11 @@ HUTK_HD uint32_t pair_mix(uint32_t l, uint32_t r) {
            ((uint32_t)((uint64_t)(r & 0xFFFFFFu) * 0x85EBCBu) + 0x165667B1u);
 #endif
 }
-HUTK_HD uint32_t pair_slot1(uint32_t t) {
-    t ^= t >> 15;
-    return t ^ (t >> 7);
+HUTK_HD uint32_t pair_bucket1(uint32_t t, uint32_t shift) { return t >> shift; }
+HUTK_HD uint32_t pair_bucket2(uint32_t t, uint32_t shift) {
+    const uint32_t b = (t * 0x9E3779B1u) >> shift;
+    return b == (t >> shift) ? b ^ 1u : b;
 }
-HUTK_HD uint32_t pair_slot2(uint32_t t) { return ((t >> 13) | (t << 19)) ^ (t >> 9) ^ (t << 3); }
-HUTK_HD uint32_t pair_hash(uint32_t l, uint32_t r) { return pair_slot1(pair_mix(l, r)); }
-HUTK_HD uint32_t pair_hash2(uint32_t l, uint32_t r) { return pair_slot2(pair_mix(l, r)); }
 // whole-word table: 16 raw bytes (zero padded) as four dwords
 HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     uint32_t x = k0 ^ ((k1 << 13) | (k1 >> 19)) ^ ((k2 << 7) | (k2 >> 25)) ^ ((k3 << 21) | (k3 >> 11));
@@ -121,10 +125,11 @@ struct Tables {
     bool ident_ids = false;     // id(sym) == sym for every vocabulary symbol
     std::vector<int32_t> sym_id;  // [n_sym]
 
-    // (left, right) -> merged symbol, open addressing, linear probing
+    // (left, right) -> merged symbol: buckets of two entries (see above); pair_slots.size() == 2 << (32 - pair_shift)
     std::vector<uint64_t> pair_slots;
-    uint32_t pair_mask = 0;
+    uint32_t pair_shift = 0;   // bucket = hash >> pair_shift
     int64_t n_pairs = 0;
+    int64_t n_pairs_second = 0;  // pairs that live in their second bucket
 
     // initial symbol of a source item
     //   byte-encoder mode: item = input byte

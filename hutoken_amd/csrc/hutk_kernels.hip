@@ -49,27 +49,34 @@ namespace hutk {
 // ------------------------------------------------------------------------
 // table lookups
 // ------------------------------------------------------------------------
-// pair slot: x = left | (right & 0xFFF) << 20, y = right >> 12 | merged << 8 (hutk_internal.h).
-// Two-choice cuckoo table: the pair is in slot hash or slot hash2 or absent.
-struct PairProbe { uint2 a, b; };
+// Pair table (hutk_internal.h): one 16-byte bucket of two entries per lookup.  The pair is in its first bucket, or
+// -- rarely, and announced by a filter bit in the first bucket -- in its second, or absent.
+struct PairProbe { uint4 b; uint32_t t; };
 __device__ __forceinline__ PairProbe pair_issue(const DevTables& T, uint32_t l, uint32_t r) {
     PairProbe p;
-    const uint32_t t = pair_mix(l, r);
-    p.a = T.pair_slots[pair_slot1(t) & T.pair_mask];
-    p.b = T.pair_slots[pair_slot2(t) & T.pair_mask];
+    p.t = pair_mix(l, r);
+    p.b = T.pair_buckets[pair_bucket1(p.t, T.pair_shift)];
     return p;
 }
-__device__ __forceinline__ uint32_t pair_resolve(const PairProbe& p, uint32_t l, uint32_t r) {
-    const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
-    // an empty slot is all ones, which is also the key pattern of (SYM_UNK, SYM_UNK): its merged field
-    // then reads 0xFFFFFF, which no entry has
+__device__ __forceinline__ uint32_t pair_match(const uint4 b, uint32_t k0, uint32_t k1) {
+    // w1 of the matching entry, or all ones
     // (bitwise on purpose: with && the compiler loads .x first and .y only on a match -- a second round trip)
-    const uint32_t da = (p.a.x ^ k0) | ((p.a.y ^ k1) & 0xFFu), db = (p.b.x ^ k0) | ((p.b.y ^ k1) & 0xFFu);
-    const uint32_t y = da == 0 ? p.a.y : db == 0 ? p.b.y : 0xFFFFFFFFu;
-    return y == 0xFFFFFFFFu ? SYM_NONE : y >> 8;
+    const uint32_t da = (b.x ^ k0) | ((b.y ^ k1) & 0xFFu), db = (b.z ^ k0) | ((b.w ^ k1) & 0xFFu);
+    return da == 0 ? b.y : db == 0 ? b.w : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ uint32_t pair_resolve(const DevTables& T, const PairProbe& p, uint32_t l, uint32_t r) {
+    const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
+    uint32_t y = pair_match(p.b, k0, k1);
+    if (y == 0xFFFFFFFFu) {
+        const uint32_t filter = (p.b.y >> 28) | ((p.b.w >> 28) << 4);
+        if ((filter >> (p.t & 7u)) & 1u)  // some pair with this filter bit moved on to its second bucket
+            y = pair_match(T.pair_buckets[pair_bucket2(p.t, T.pair_shift)], k0, k1);
+    }
+    const uint32_t m = (y >> 8) & 0xFFFFFu;  // PAIR_ABSENT for an empty entry matched by (SYM_UNK, SYM_UNK) and for y == all ones
+    return m == PAIR_ABSENT ? SYM_NONE : m;
 }
 __device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, uint32_t r) {
-    return pair_resolve(pair_issue(T, l, r), l, r);
+    return pair_resolve(T, pair_issue(T, l, r), l, r);
 }
 
 __device__ __forceinline__ uint32_t char_lookup(const DevTables& T, uint32_t packed) {
@@ -253,6 +260,11 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //   HUTK_CHAR_EU      the same outside byte-encoder mode (6: LDS-limited)
 //   HUTK_LDS_TIGHT    1: pool and merge array sized so that 8 workgroups fit a CU's LDS; 0: roomier (7)
 //   HUTK_SPLIT_SWAR   1: classify with the SWAR mask algebra instead of the automaton
+//   HUTK_FAST_MERGE   0: the general merge loop also where the short form (packed keys) applies
+//   HUTK_POOL_SORT    1: the merge pool sorted by unit count (counting sort) instead of two classes (more than 8 units /
+//                     the rest); measured with 8 tiles per workgroup: -2.5 %, the two extra passes cost more than the
+//                     more even chunks return
+//   HUTK_STAGE_RUN    1: a tile's symbols go to HBM through LDS as 16-byte stores instead of lane by lane (measured: -1 %)
 //   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
@@ -327,15 +339,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #ifndef HUTK_LDS_TIGHT
 #define HUTK_LDS_TIGHT 1
 #endif
-    constexpr int POOL_CAP = (HUTK_LDS_TIGHT ? 64 : 128) * WAVES, POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
+    constexpr int POOL_CAP = (HUTK_LDS_TIGHT ? 64 : 128) * WAVES;
+    [[maybe_unused]] constexpr int POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
     static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
 #ifndef HUTK_FAST_MERGE
 #define HUTK_FAST_MERGE 1
+#endif
+#ifndef HUTK_STAGE_RUN
+#define HUTK_STAGE_RUN 0
+#endif
+#ifndef HUTK_POOL_SORT
+#define HUTK_POOL_SORT 0
 #endif
     // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
     constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
+#if HUTK_POOL_SORT
+    __shared__ uint32_t pool_hist[33], pool_rank[33], pool_start[33];  // merge words by unit count; placed so far; first pool entry of that count
+    constexpr uint32_t POOL_EMPTY = 0xFFFFFFFFu;
+#endif
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
@@ -689,6 +712,48 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
 #endif
     for (;;) {
+#if HUTK_POOL_SORT
+        // The pool is SORTED by unit count, longest words first (a counting sort: histogram, scan, cursors), so that
+        // the 64 words of a chunk need about the same number of trips and the long tail sits in the first chunk only.
+        if (threadIdx.x < 33) { pool_hist[threadIdx.x] = 0; pool_rank[threadIdx.x] = 0; }
+        if (threadIdx.x == 0) pool_cnt[2] = 0;
+        __syncthreads();  // (also: every wavefront is done with the splitter tables that share the pool's LDS)
+        for (int i = threadIdx.x; i < POOL_CAP; i += 64 * WAVES) pool[i] = POOL_EMPTY;
+        uint32_t pending = 0;
+        if (tile_ok) {
+            pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
+            for (uint32_t m = pending; m; m &= m - 1)
+                atomicAdd(&pool_hist[word_units(me, 16 * lane + __builtin_ctz(m))], 1u);
+        }
+        __syncthreads();
+        uint32_t n_pool;
+        {   // lane i <-> words of 32 - i units: where their stretch of the pool begins.  Every wavefront computes and
+            // stores the same values (a shuffle inside the divergent loop below would read inactive lanes).
+            const uint32_t start = wave_excl_scan(lane <= 30 ? pool_hist[32 - lane] : 0u, lane, &n_pool);
+            if (lane <= 30) pool_start[32 - lane] = start;
+            wave_sync();
+            if (tile_ok) {
+                for (uint32_t m = pending; m; m &= m - 1) {
+                    const int j = __builtin_ctz(m);
+                    const int ws = 16 * lane + j;
+                    const int n = word_units(me, ws);
+                    const uint32_t idx = pool_start[n] + atomicAdd(&pool_rank[n], 1u);
+                    if (idx >= (uint32_t)POOL_CAP) continue;  // the shortest words wait for the next epoch
+                    const uint32_t moff = atomicAdd(&pool_cnt[2], (uint32_t)n);
+                    if (moff + n > (uint32_t)M_ARENA) continue;  // no room in m this epoch: the entry stays empty
+                    pool[idx] = (moff << 16) | (uint32_t)((wv << 10) | ws);
+                    pending &= ~(1u << j);
+                }
+                reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)pending;
+            }
+        }
+        __syncthreads();
+        n_pool = min(n_pool, (uint32_t)POOL_CAP);
+        for (uint32_t base = 64u * wv; base < n_pool; base += 64u * WAVES) {
+            const uint32_t wi = base + lane;
+            const uint32_t entry = wi < n_pool ? pool[wi] : POOL_EMPTY;
+            bool have = entry != POOL_EMPTY;
+#else
         if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
         __syncthreads();
         uint32_t pending = 0;
@@ -716,6 +781,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             const uint32_t wi = base + lane;
             bool have = wi < n_pool;
             const uint32_t entry = have ? (wi < n_long ? pool[wi] : pool[POOL_CAP - 1 - (wi - n_long)]) : 0u;
+#endif
             Tile& X = L[(entry >> 10) & 63u];  // the word's tile
             const int ws = entry & 1023;
             SymT* Sw = X.S + ws;
@@ -815,7 +881,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         const PairProbe s2 = pair_issue(T, sl, merged);
                         cand &= ~((1u << q) | (1u << p) | (1u << p0));
                         best = scan_key(cand);
-                        uint32_t mr = pair_resolve(s1, merged, sr), ml = pair_resolve(s2, sl, merged);
+                        uint32_t mr = pair_resolve(T, s1, merged, sr), ml = pair_resolve(T, s2, sl, merged);
                         mr = right ? mr : SYM_NONE;
                         ml = left ? ml : SYM_NONE;
                         Mw[p0] = (SymT)ml;  // first: without a left neighbour p0 == p
@@ -870,7 +936,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                             for (int j = 0; j < 4; j++) {
                                 const int i = i0 + j;
                                 if (i + 1 < n) {
-                                    const uint32_t m = pair_resolve(pr[j], sl[j], sl[j + 1]);
+                                    const uint32_t m = pair_resolve(T, pr[j], sl[j], sl[j + 1]);
                                     Mw[i] = Sym<SymT>::narrow(m);
                                     if (m != SYM_NONE) cand |= 1u << i;
                                 }
@@ -920,8 +986,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         br = 0xFFFFFFFFu;
                         scan_best(cand, Mw, br, bp, bm);
                         // the two new pairs
-                        const uint32_t mr = right ? pair_resolve(s1, merged, sr) : SYM_NONE;
-                        const uint32_t ml = left ? pair_resolve(s2, sl, merged) : SYM_NONE;
+                        const uint32_t mr = right ? pair_resolve(T, s1, merged, sr) : SYM_NONE;
+                        const uint32_t ml = left ? pair_resolve(T, s2, sl, merged) : SYM_NONE;
                         if (right) {
                             const SymT mn = Sym<SymT>::narrow(mr);
                             Mw[p] = mn;
@@ -1012,9 +1078,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    // symbols in the width the LDS arrays use (k_gather widens them and turns them into ids)
+    // symbols in the width the LDS arrays use (k_gather widens them and turns them into ids).  Byte-encoder mode:
+    // the run is collected in LDS (the tile's byte window is no longer needed) and leaves as whole 16-byte stores;
+    // a lane's ids are few and scattered 2-byte global stores cost an address cycle each.  A tile with more ids
+    // than the window holds, and the other mode (whose epilogue still reads the bytes), store directly.
     SymT* run_out = reinterpret_cast<SymT*>(W.run) + tile * RUN_STRIDE;
-    {
+    constexpr uint32_t STAGE_CAP = (uint32_t)(sizeof(me.sb) / sizeof(SymT));
+    const bool staged = BYTE_MODE && HUTK_STAGE_RUN && n_dense <= STAGE_CAP;  // the same for the whole wavefront
+    auto emit_run = [&](SymT* dst) {
         uint32_t pos = run & 0xFFFFu, eidx = run >> 16;
         uint32_t ev = live16 | exc16;
         if (PREFIXED && T.has_prefix) ev |= own;  // arena words have no live bit of their own
@@ -1046,14 +1117,23 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const int a = arena_at(ws);
                 if (a >= 0) {
                     for (uint32_t sv = arena_live[a]; sv; sv &= sv - 1)
-                        run_out[pos++] = arenaS[a * ARENA_W + __builtin_ctz(sv)];
+                        dst[pos++] = arenaS[a * ARENA_W + __builtin_ctz(sv)];
                     continue;
                 }
                 const uint32_t na = alone_ids(ws);
-                for (uint32_t i = 0; i < na; i++) run_out[pos++] = Sym<SymT>::narrow(T.prefix_alone_syms[i]);
+                for (uint32_t i = 0; i < na; i++) dst[pos++] = Sym<SymT>::narrow(T.prefix_alone_syms[i]);
             }
-            if ((live16 >> j) & 1u) run_out[pos++] = S[ws];  // stores only: nothing here waits
+            if ((live16 >> j) & 1u) dst[pos++] = S[ws];  // stores only: nothing here waits
         }
+    };
+    if (staged) {
+        emit_run(reinterpret_cast<SymT*>(sb));
+        wave_sync();
+        const uint32_t nvec = (n_dense * (uint32_t)sizeof(SymT) + 15u) / 16u;
+        for (uint32_t v = lane; v < nvec; v += 64)
+            reinterpret_cast<uint4*>(run_out)[v] = reinterpret_cast<const uint4*>(sb)[v];
+    } else {
+        emit_run(run_out);
     }
     wave_sync();
     HUTK_STAMP(7);
@@ -1341,7 +1421,7 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (i0 + j + 1 < n) {
-                            const uint32_t m = pair_resolve(pr[j], sy[j], sy[j + 1]);
+                            const uint32_t m = pair_resolve(T, pr[j], sy[j], sy[j + 1]);
                             Mm[(i0 + j) * 64 + lane] = Sym<SymT>::narrow(m);
                             if (m != SYM_NONE) cand |= 1ull << (i0 + j);
                         }
@@ -1394,7 +1474,7 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
                 br = 0xFFFFFFFFu;
                 scan4(cand, br, bp, bm);
                 if (right) {
-                    const uint32_t m = pair_resolve(pr, merged, sr);
+                    const uint32_t m = pair_resolve(T, pr, merged, sr);
                     Mm[p * 64 + lane] = Sym<SymT>::narrow(m);
                     if (m != SYM_NONE) {
                         cand |= 1ull << p;
@@ -1403,7 +1483,7 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
                     }
                 }
                 if (left) {
-                    const uint32_t m = pair_resolve(pl, sl, merged);
+                    const uint32_t m = pair_resolve(T, pl, sl, merged);
                     Mm[p0 * 64 + lane] = Sym<SymT>::narrow(m);
                     if (m != SYM_NONE) {
                         cand |= 1ull << p0;
@@ -1510,7 +1590,7 @@ __global__ __launch_bounds__(64) void k_exc_quad(DevTables T, BatchArgs A, Works
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (have && lo + k0 + j < n)
-                    Mg[lo + k0 + j] = (lo + k0 + j + 1 < n) ? pair_resolve(pr[j], sy[j], sy[j + 1]) : SYM_NONE;
+                    Mg[lo + k0 + j] = (lo + k0 + j + 1 < n) ? pair_resolve(T, pr[j], sy[j], sy[j + 1]) : SYM_NONE;
         }
         wave_sync();
         bool dirty = true;
@@ -1555,8 +1635,8 @@ __global__ __launch_bounds__(64) void k_exc_quad(DevTables T, BatchArgs A, Works
             const uint32_t sr = (act && q >= 0 && q2 >= 0) ? Sg[q2] : 0u;
             const uint32_t sl = (act && p0 >= 0) ? Sg[p0] : 0u;
             const PairProbe prr = pair_issue(T, merged, sr), prl = pair_issue(T, sl, merged);
-            const uint32_t mr = (act && q >= 0 && q2 >= 0) ? pair_resolve(prr, merged, sr) : SYM_NONE;
-            const uint32_t ml = (act && p0 >= 0) ? pair_resolve(prl, sl, merged) : SYM_NONE;
+            const uint32_t mr = (act && q >= 0 && q2 >= 0) ? pair_resolve(T, prr, merged, sr) : SYM_NONE;
+            const uint32_t ml = (act && p0 >= 0) ? pair_resolve(T, prl, sl, merged) : SYM_NONE;
             wave_sync();  // everybody has read S before the owners write
             if (act && q >= 0) {
                 if (l == (p >> 4)) {

@@ -10,6 +10,7 @@
 //   pretokenizer    src/pretokenizer.c:102-168
 //   rank of a pair  src/core.c:700-722: the vocabulary id of the concatenation
 #include <algorithm>
+#include <functional>
 #include <cerrno>
 #include <climits>
 #include <cstdio>
@@ -200,41 +201,90 @@ uint32_t pow2_at_least(uint64_t n) {
 }
 
 
-// (left, right) -> merged entries into the two-choice cuckoo pair table
-LoadError finish_pair_table(Tables& T, const std::vector<uint64_t>& entries) {
+// (left, right) -> merged entries into the bucketed pair table (hutk_internal.h)
+LoadError finish_pair_table(Tables& T, const std::vector<uint64_t>& entries_in) {
     T.n_sym = (uint32_t)T.sym_id.size();
     if (T.n_sym >= SYM_UNK)
         return fail(HUTK_E_UNSUPPORTED, "vocabulary too large for 20-bit symbols");
-    T.n_pairs = (int64_t)entries.size();
-    // two-choice cuckoo table at load <= 0.4; a placement failure (not seen in practice) doubles it
-    auto left_of = [&](uint32_t i) { return (uint32_t)entries[i] & 0xFFFFFu; };
-    auto right_of = [&](uint32_t i) {
-        return ((uint32_t)entries[i] >> 20) | (((uint32_t)(entries[i] >> 32) & 0xFFu) << 12);
-    };
-    uint32_t cap = pow2_at_least(entries.size() * 5 / 2 + 16);
-    std::vector<uint32_t> where;
+    T.n_pairs = (int64_t)entries_in.size();
+    auto left_of = [](uint64_t e) { return (uint32_t)e & 0xFFFFFu; };
+    auto right_of = [](uint64_t e) { return ((uint32_t)e >> 20) | (((uint32_t)(e >> 32) & 0xFFu) << 12); };
+    // ascending merged symbol: the low ranks (frequent merges) are placed first and get their first bucket
+    std::vector<uint64_t> entries(entries_in);
+    std::stable_sort(entries.begin(), entries.end(),
+                     [](uint64_t x, uint64_t y) { return (x >> 40) < (y >> 40); });
+    uint32_t n_buckets = pow2_at_least(entries.size() * 5 / 4 + 16);  // two entries each: load <= 0.4
     for (int attempt = 0;; attempt++) {
-        if (cuckoo_place(entries.size(), cap,
-                         [&](uint32_t i) { return pair_hash(left_of(i), right_of(i)); },
-                         [&](uint32_t i) { return pair_hash2(left_of(i), right_of(i)); }, where))
+        int64_t n_second_extra = 0;
+        uint32_t shift = 32;
+        while ((1ull << (32 - shift)) < n_buckets) shift--;
+        std::vector<uint64_t> slots((size_t)n_buckets * 2, PAIR_EMPTY);
+        auto put = [&](uint32_t b, uint64_t e) -> bool {
+            for (int k = 0; k < 2; k++)
+                if (slots[2 * (size_t)b + k] == PAIR_EMPTY) { slots[2 * (size_t)b + k] = e; return true; }
+            return false;
+        };
+        std::vector<uint64_t> second;
+        auto mix_of = [&](uint64_t e) { return pair_mix(left_of(e), right_of(e)); };
+        for (uint64_t e : entries)
+            if (!put(pair_bucket1(mix_of(e), shift), e)) second.push_back(e);
+        // A pair that found its first bucket full goes to its second one.  When that is full too, a resident moves
+        // to the other of ITS two buckets, and so on for a few steps (a bucket never loses an entry on the way, so
+        // the first bucket of a pair that lives in its second one stays full).  Every pair stays within its two
+        // buckets: a lookup never reads more than two.
+        std::function<bool(uint32_t, uint64_t, int)> into = [&](uint32_t b, uint64_t e, int depth) -> bool {
+            if (put(b, e)) return true;
+            if (depth == 0) return false;
+            for (int k = 0; k < 2; k++) {
+                const uint64_t x = slots[2 * (size_t)b + k];
+                const uint32_t tx = mix_of(x), x1 = pair_bucket1(tx, shift), x2 = pair_bucket2(tx, shift);
+                const uint32_t alt = x1 == b ? x2 : x1;
+                slots[2 * (size_t)b + k] = e;
+                if (into(alt, x, depth - 1)) return true;
+                slots[2 * (size_t)b + k] = x;
+            }
+            return false;
+        };
+        bool ok = true;
+        for (uint64_t e : second) {
+            const uint32_t t = mix_of(e);
+            if (!into(pair_bucket2(t, shift), e, 5) && !into(pair_bucket1(t, shift), e, 5)) { ok = false; break; }
+        }
+        if (ok) {  // filter bits: one per pair that ended up in its second bucket, in the top nibbles of its first bucket's entries
+            for (size_t i = 0; i < slots.size(); i++) {
+                const uint64_t x = slots[i];
+                if (x == PAIR_EMPTY) continue;
+                const uint32_t tx = mix_of(x & 0x0FFFFFFFFFFFFFFFull), x1 = pair_bucket1(tx, shift);
+                if ((uint32_t)(i >> 1) == x1) continue;
+                const uint32_t f = tx & 7u;
+                slots[2 * (size_t)x1 + (f >> 2)] |= (uint64_t)(1u << (f & 3u)) << 60;
+                n_second_extra++;
+            }
+        }
+        if (ok) {
+            T.pair_shift = shift;
+            T.pair_slots.swap(slots);
+            T.n_pairs_second = n_second_extra;
             break;
-        if (attempt == 4) return fail(HUTK_E_UNSUPPORTED, "pair table could not be built");
-        cap *= 2;
+        }
+        if (attempt == 5) return fail(HUTK_E_UNSUPPORTED, "pair table could not be built");
+        n_buckets *= 2;
     }
-    T.pair_mask = cap - 1;
-    T.pair_slots.assign(cap, SLOT_EMPTY);
-    for (size_t i = 0; i < entries.size(); i++) T.pair_slots[where[i]] = entries[i];
     T.sym16 = T.n_sym < 0xFFF0u;
     return {};
 }
 
 uint32_t host_pair_lookup(const Tables& T, uint32_t l, uint32_t r) {
     const uint32_t k0 = l | ((r & 0xFFFu) << 20), k1 = r >> 12;
-    for (uint32_t h : {pair_hash(l, r) & T.pair_mask, pair_hash2(l, r) & T.pair_mask}) {
-        const uint64_t sl = T.pair_slots[h];
-        if (sl != SLOT_EMPTY && (uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1)
-            return (uint32_t)(sl >> 40);
-    }
+    const uint32_t t = pair_mix(l, r);
+    for (uint32_t b : {pair_bucket1(t, T.pair_shift), pair_bucket2(t, T.pair_shift)})
+        for (int k = 0; k < 2; k++) {
+            const uint64_t sl = T.pair_slots[2 * (size_t)b + k];
+            if ((uint32_t)sl == k0 && (((uint32_t)(sl >> 32)) & 0xFFu) == k1) {
+                const uint32_t m = (uint32_t)(sl >> 40) & 0xFFFFFu;
+                return m == PAIR_ABSENT ? SYM_NONE : m;
+            }
+        }
     return SYM_NONE;
 }
 

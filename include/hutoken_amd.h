@@ -164,6 +164,10 @@ int hutk_table_stats(const hutk_ctx* ctx, int64_t* out8);
  * ("encode tiles") and the whole enqueue.  Synchronises on those events. */
 int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
 
+/* Diagnostic: pairs of the (left, right) -> merged table that live in their second bucket (a lookup for them
+ * costs two loads instead of one). */
+int64_t hutk_debug_pairs_second(const hutk_ctx* ctx);
+
 /* Diagnostic build aid: clock64 stamps at the phase boundaries of the tile kernel.
  * hutk_debug_profile(ctx, 1), run a batch, then hutk_debug_profile_read returns the
  * mean shader cycles per phase over the first n_tiles tiles (out10[0] = their sum,

@@ -96,6 +96,30 @@ class RefTokenizer:
     def batch_encode(self, texts, num_threads=1):
         return self.m.batch_encode(texts, num_threads)
 
+    def seam_batch(self, data, offsets, num_threads):
+        """The reference's C core without its list marshalling: num_threads pthreads calling the internal
+        seam encode(struct EncodeTask*) once per document of a packed batch (oracle/ref_seam.c).
+        -> (total ids, seconds)"""
+        import ctypes as C
+
+        import numpy as np
+        lib = os.path.join(_HERE, "_build", "libref_seam.so")
+        src = os.path.join(_HERE, "ref_seam.c")
+        if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "_build/libref_seam.so"])
+        L = C.CDLL(lib)
+        L.ref_seam_batch.restype = C.c_int
+        L.ref_seam_batch.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n_ids, sec = C.c_int64(0), C.c_double(0)
+        rc = L.ref_seam_batch(os.fsencode(so_path()), data.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                              int(num_threads), C.byref(n_ids), C.byref(sec))
+        if rc:
+            raise RuntimeError("ref_seam_batch failed (%d)" % rc)
+        return n_ids.value, sec.value
+
     def decode(self, ids):
         return self.m.decode(ids)
 
