@@ -9,22 +9,29 @@ ids) on N MI355X, the metric BASELINE.json names.
 A step = one pass of the batch encode path (hutk_encode_batch_device: every kernel
 of the pipeline) over one batch that is ALREADY RESIDENT IN HBM: packed UTF-8 bytes
 + int64 offsets in, int32 ids + int64 offsets out, all device buffers.
-Workload at every N: corpus C3, 1,000,000 synthetic documents per GPU, mean 512 B,
-mixed UTF-8 (hutoken_amd/csrc/hutk_synth.c), vocabulary VG (data/vg50257_*).
-Documents shard trivially: rank r encodes documents [r*1M, (r+1)*1M) of the
-generator with its own context; the only collective is an all-gather of the
-per-rank id totals (RCCL), inside every timed step.  Scaling is therefore weak.
+Workload (`value`, scaling "weak"): corpus C3, 1,000,000 synthetic documents per GPU,
+mean 512 B, mixed UTF-8 (hutoken_amd/csrc/hutk_synth.c), vocabulary VG (data/vg50257_*).
+Documents shard trivially: rank r encodes documents [r*1M, (r+1)*1M) of the generator
+with its own context; the only collective is an all-gather of the per-rank id totals
+(RCCL), inside every timed step.
 
 The JSON line also carries
-  roofline      algorithmic HBM bytes of the dominant kernel (k_tiles) / its
-                mean duration from HIP events recorded around it on the launch
-                stream in every timed step, against 8 TB/s
-  cpu_baseline  the reference itself (oracle/_ref, compiled from the reference
-                sources; kind "reference") or this repo's C restatement (kind
-                "port") timed on the host cores, on a bounded sample of the same
-                workload, rank 0 at N=1 only.
+  roofline      algorithmic HBM bytes of the dominant kernel (k_tiles) / its mean duration from HIP
+                events recorded around it on the launch stream in every timed step, against 8 TB/s;
+                `issue`: the limit that actually binds -- VALU wave-instructions per launch from the
+                committed PMC profile x 4 cycles / (1024 SIMDs x the launch's busy cycles)
+  strong        (N > 1) BASELINE config 4: the SAME 1,000,000 documents cut into N byte-balanced
+                contiguous shards (hutoken_amd.sharding.shard_by_bytes), rank r generating only its range
+  end_to_end    (N = 1) the drop-in's host entry points on the same workload: page-locked host buffers in
+                and out through hutk_encode_batch (PCIe inclusive), and the Python list API on a sample
+  secondary     (N = 1) other configurations and off-distribution text, device-resident, 200k documents each
+  cpu_baseline  (N = 1) the reference itself (oracle/_ref, compiled from the reference sources; kind
+                "reference") timed on the host cores on a bounded sample of the same workload: its list API
+                (`value`) and, marshalling-free, its C core through the internal encode() seam (`seam`).
+Everything measured on the GPU is checked against the oracle on its first 2000 documents.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -33,12 +40,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD = 1024           # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
+VERIFY_DOCS = 2000
 
 
 def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores, mp=None):
     """Times the CPU path on the first n_sample documents of the workload."""
-    import numpy as np
     from hutoken_amd import synth
     data, offs = synth.corpus(corpus_name, n_sample)
     nbytes = int(offs[-1])
@@ -56,6 +64,13 @@ def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores, mp=None):
                        note="hutoken.batch_encode(list[str], num_threads=cores) of the reference "
                             "compiled from its own sources, list marshalling included",
                        n_ids=int(sum(len(r) for r in res)))
+            try:  # the C core alone: `cores` pthreads on the reference's internal encode() seam, no Python objects
+                n_ids, sec = tok.seam_batch(data, offs, cores)
+                out["seam"] = {"value": nbytes / sec / 1e9, "unit": "GB/s", "cores": cores, "n_ids": int(n_ids),
+                               "note": "void encode(struct EncodeTask*) of the compiled reference (core.h:11) called once "
+                                       "per document from `cores` pthreads (oracle/ref_seam.c): no list marshalling, no GIL"}
+            except Exception as e:
+                out["seam_error"] = repr(e)
             return out
     except Exception as e:  # fall through to the port
         out["reference_error"] = repr(e)
@@ -71,21 +86,166 @@ def cpu_baseline(vp, sp, kw, corpus_name, n_sample, cores, mp=None):
     return out
 
 
-def committed_traffic(n_bytes):
-    """HBM-side bytes of one k_tiles launch from the PMC passes of the last committed profile of THIS workload
-    (profiles/<tag>_traffic.json, written by tools/summarize_rocprof.py from separate `rocprofv3 --pmc` runs of
-    the same bench command: counters cannot be collected inside a timed run).  None when there is no profile
-    of a batch of this size."""
-    import glob
+def committed_profile(n_bytes, suffix):
+    """The last committed profiles/<tag>_<suffix>.json of THIS workload (written by tools/summarize_rocprof.py from
+    separate `rocprofv3 --pmc` runs of the same bench command: counters cannot be collected inside a timed run)."""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{suffix}.json"))):
         try:
             t = json.load(open(f))
         except Exception:
             continue
         if t.get("workload_bytes") == n_bytes:
-            best = (float(t["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT))
+            best = (t, os.path.relpath(f, ROOT))
     return best if best else (None, None)
+
+
+class DeviceBatch:
+    """A packed batch resident in HBM with its output buffers; run() enqueues one pass of the pipeline."""
+
+    def __init__(self, ctx, data, offs, dev):
+        import torch
+        self.ctx, self.dev = ctx, dev
+        self.n_docs, self.n_bytes = len(offs) - 1, int(offs[-1])
+        self.d_bytes = torch.from_numpy(data).to(dev)
+        self.d_offs = torch.from_numpy(offs).to(dev)
+        self.cap = ctx.ids_capacity(self.n_bytes, self.n_docs)
+        self.d_ids = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.d_oo = torch.empty(self.n_docs + 1, dtype=torch.int64, device=dev)
+        self.d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def run(self):
+        self.ctx.encode_device(self.d_bytes.data_ptr(), self.d_offs.data_ptr(), self.n_docs, self.n_bytes,
+                               self.d_ids.data_ptr(), self.cap, self.d_oo.data_ptr(), 0, self.d_err.data_ptr(),
+                               self.stream)
+
+    def check_err(self):
+        code = int(self.d_err.item())
+        if code != 0:
+            raise SystemExit(f"device-side error {code}")
+
+    def n_ids(self):
+        return int(self.d_oo[self.n_docs].item())
+
+    def verify(self, orc, data, offs, cores):
+        """First VERIFY_DOCS documents against the oracle: offsets and every id."""
+        import numpy as np
+        k = min(VERIFY_DOCS, self.n_docs)
+        ids_o, oo_o, _ = orc.encode_packed(data[: int(offs[k])], offs[: k + 1], min(cores, 8))
+        oo_g = self.d_oo[: k + 1].cpu().numpy()
+        ids_g = self.d_ids[: int(oo_g[k])].cpu().numpy()
+        if not (np.array_equal(oo_o, oo_g) and np.array_equal(ids_o, ids_g)):
+            raise SystemExit("PARITY FAILURE: GPU ids differ from the oracle")
+        return True
+
+
+def timed(batch, steps, warmup, sync):
+    """-> (seconds per step, mean k_tiles ms) of `steps` passes after `warmup` untimed ones."""
+    for _ in range(warmup):
+        batch.run()
+    sync()
+    batch.check_err()
+    tile_ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.run()
+        tile_ms.append(batch.ctx.last_timing()[0])
+    sync()
+    return (time.perf_counter() - t0) / steps, sum(tile_ms) / len(tile_ms)
+
+
+def secondary_runs(dev, dev_index, cores, no_verify):
+    """Other configurations, 200k documents each, device-resident, checked against the oracle."""
+    import torch
+    from hutoken_amd import _capi, data as hdata, synth
+    from oracle import oracle as O
+    sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
+    out = []
+    cases = [("C2 x VG (BASELINE config 2: ASCII)", "VG", False, lambda: synth.corpus("C2", 200_000)),
+             ("C5 x VL (config 5: Hungarian text, Llama-shaped vocab, prefix, non-byte mode)", "VL", False,
+              lambda: synth.corpus("C5", 200_000)),
+             ("C3 x VG + merges file (id-keyed merge path)", "VG", True, lambda: synth.corpus("C3", 200_000)),
+             ("random words of 17-31 letters x VG (every word through the merge loop)", "VG", False,
+              lambda: synth.random_words(17, 31, 200_000, 20)),
+             ("random words of 33-62 letters x VG (every word through the exception kernels)", "VG", False,
+              lambda: synth.random_words(33, 62, 200_000, 10))]
+    ctxs = {}
+    for label, vocab, merges, gen in cases:
+        key = (vocab, merges)
+        vp, sp, kw = hdata.vocab_files(vocab)
+        mp = hdata.merges_file(vocab) if merges else None
+        if key not in ctxs:
+            ctxs[key] = (_capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=dev_index, merges_path=mp),
+                         O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp))
+        ctx, orc = ctxs[key]
+        d, o = gen()
+        b = DeviceBatch(ctx, d, o, dev)
+        sec, tile_ms = timed(b, 5, 2, sync)
+        ok = None if no_verify else b.verify(orc, d, o, cores)
+        out.append({"workload": label, "docs": b.n_docs, "bytes": b.n_bytes, "ids": b.n_ids(),
+                    "value": round(b.n_bytes / sec / 1e9, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4),
+                    "k_tiles_ms": round(tile_ms, 4), "verified_vs_oracle": ok})
+        del b
+    return out
+
+
+def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
+    """The host entry points on the same workload (PCIe inclusive; never `value`)."""
+    import numpy as np
+    from hutoken_amd import _capi, synth
+    import hutoken_amd as hutoken
+    L = _capi.load()
+    n_docs, n_bytes = len(offs) - 1, int(offs[-1])
+    cap = ctx.ids_capacity(n_bytes, n_docs)
+    pb, po = _capi.PinnedArray(n_bytes, np.uint8), _capi.PinnedArray(n_docs + 1, np.int64)
+    pi, poo = _capi.PinnedArray(cap, np.int32), _capi.PinnedArray(n_docs + 1, np.int64)
+    pb.array[:] = data
+    po.array[:] = offs
+
+    def once():
+        rc = L.hutk_encode_batch(ctx.handle, pb.array.ctypes.data, po.array.ctypes.data, n_docs, pi.array.ctypes.data,
+                                 cap, poo.array.ctypes.data, None)
+        if rc:
+            raise SystemExit("hutk_encode_batch: " + _capi.last_error())
+    once()
+    best = 1e9
+    for _ in range(3):
+        t = time.perf_counter()
+        once()
+        best = min(best, time.perf_counter() - t)
+    k = min(VERIFY_DOCS, n_docs)
+    ok = None
+    if not no_verify:
+        ids_o, oo_o, _ = orc.encode_packed(data[: int(offs[k])], offs[: k + 1], min(cores, 8))
+        ok = bool(np.array_equal(oo_o, poo.array[: k + 1]) and np.array_equal(ids_o, pi.array[: int(oo_o[k])]))
+        if not ok:
+            raise SystemExit("PARITY FAILURE: hutk_encode_batch ids differ from the oracle")
+    out = {"packed_pinned": {"value": round(n_bytes / best / 1e9, 2), "unit": "GB/s", "ms": round(best * 1e3, 2),
+                             "docs": n_docs, "verified_vs_oracle": ok,
+                             "note": "hutk_encode_batch, page-locked host bytes+offsets in, host ids+offsets out "
+                                     "(hutk_host_alloc); chunks of whole documents, H2D / kernels / D2H overlapped"}}
+    for a in (pb, po, pi, poo):
+        a.close()
+    # the reference's own surface: list[str] -> list[list[int]]
+    n_list = min(100_000, n_docs)
+    docs = synth.docs_as_str(data[: int(offs[n_list])], offs[: n_list + 1])
+    hutoken.initialize(vp, sp, device=dev_index, **kw)
+    hutoken.batch_encode(docs[:1000], 1)
+    t = time.perf_counter()
+    res = hutoken.batch_encode(docs, cores)
+    dt = time.perf_counter() - t
+    okl = None
+    if not no_verify:
+        want = orc.batch_encode(docs[:VERIFY_DOCS], min(cores, 8))
+        okl = res[:VERIFY_DOCS] == want
+        if not okl:
+            raise SystemExit("PARITY FAILURE: batch_encode ids differ from the oracle")
+    nb = int(offs[n_list])
+    out["list_api"] = {"value": round(nb / dt / 1e9, 4), "unit": "GB/s", "ms": round(dt * 1e3, 1), "docs": n_list,
+                       "verified_vs_oracle": okl,
+                       "note": "hutoken_amd.batch_encode(list[str]) -> list[list[int]], CPython object traffic included"}
+    return out
 
 
 def main():
@@ -94,16 +254,22 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--corpus", default="C3", choices=["C2", "C3", "C5"])
+    ap.add_argument("--vocab", default="VG", choices=["VG", "VL"],
+                    help="VG: GPT-2 shape (the BASELINE metric); VL: Llama/SentencePiece shape -- with --corpus C5 this is "
+                         "BASELINE config 5")
     ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: the corpus size)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="what `value` is at N > 1: weak = the corpus per GPU; strong = ONE corpus cut into N byte-balanced "
+                         "shards.  The default run reports weak as `value` and, at N > 1, strong beside it")
     ap.add_argument("--cpu-docs", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end and secondary (N = 1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code "
                          "path where RCCL cannot run, e.g. two ranks sharing one GPU with HUTK_BENCH_DEVICE=0)")
     ap.add_argument("--merges", action="store_true",
-                    help="secondary configuration: the id-keyed merge path (VG with its merges file, SURVEY 8 f-1); "
-                         "the default and BASELINE metric is the string-keyed path")
+                    help="the id-keyed merge path (the vocabulary with its merges file, SURVEY 8 f-1) as the main workload")
     args = ap.parse_args()
 
     import numpy as np
@@ -128,107 +294,165 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from hutoken_amd import _capi, data as hdata, synth
-    vp, sp, kw = hdata.vocab_files("VG")
-    mp = hdata.merges_file("VG") if args.merges else None
+    from hutoken_amd import _capi, data as hdata, sharding, synth
+    vp, sp, kw = hdata.vocab_files(args.vocab)
+    mp = hdata.merges_file(args.vocab) if args.merges else None
     ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=dev_index, merges_path=mp)
 
-    n_docs = args.docs or synth.KINDS[args.corpus][2]
+    n_corpus = args.docs or synth.KINDS[args.corpus][2]
     cores = os.cpu_count() or 1
-    t_gen = time.perf_counter()
-    data, offs = synth.corpus(args.corpus, n_docs, first_doc=rank * n_docs,
-                              threads=max(2, min(32, cores // max(world, 1))))
-    t_gen = time.perf_counter() - t_gen
-    n_bytes = int(offs[-1])
-
-    d_bytes = torch.from_numpy(data).to(dev)
-    d_offs = torch.from_numpy(offs).to(dev)
-    cap = ctx.ids_capacity(n_bytes, n_docs)
-    d_ids = torch.empty(cap, dtype=torch.int32, device=dev)
-    d_oo = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
-    d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+    gen_threads = max(2, min(32, cores // max(world, 1)))
     d_tot = torch.zeros(1, dtype=torch.int64, device=cdev)
     gathered = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
-    stream = torch.cuda.current_stream(dev).cuda_stream
 
-    def step():
-        ctx.encode_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, n_bytes, d_ids.data_ptr(), cap,
-                          d_oo.data_ptr(), 0, d_err.data_ptr(), stream)
-        if world > 1:  # the path's one exchange: per-rank id totals
-            d_tot.copy_(d_oo[n_docs:n_docs + 1])
-            dist.all_gather(gathered, d_tot)
+    def sync():
+        torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if int(d_err.item()) != 0:
-        raise SystemExit(f"device-side error {int(d_err.item())}")
+    def run_mode(first_doc, n_docs):
+        """Timed region of one scaling mode on this rank's documents [first_doc, first_doc + n_docs)."""
+        t_gen = time.perf_counter()
+        data, offs = synth.corpus(args.corpus, n_docs, first_doc=first_doc, threads=gen_threads)
+        t_gen = time.perf_counter() - t_gen
+        batch = DeviceBatch(ctx, data, offs, dev)
 
-    tile_ms = []
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        tile_ms.append(ctx.last_timing()[0])  # HIP events around k_tiles on the launch stream
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tb = torch.tensor([n_bytes], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tb)
-        total_bytes = int(tb.item())
-    else:
-        total_bytes = n_bytes
-    n_ids = int(d_oo[n_docs].item())
+        def step():
+            batch.run()
+            if world > 1:  # the path's one exchange: per-rank id totals
+                d_tot.copy_(batch.d_oo[n_docs:n_docs + 1])
+                dist.all_gather(gathered, d_tot)
 
-    # parity spot check against the oracle on the first documents of this rank's shard
-    verified = None
-    if not args.no_verify:
-        from oracle import oracle as O
-        orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
-        k = min(2000, n_docs)
-        ids_o, oo_o, _ = orc.encode_packed(data[: int(offs[k])], offs[: k + 1], min(cores, 8))
-        oo_g = d_oo[: k + 1].cpu().numpy()
-        ids_g = d_ids[: int(oo_g[k])].cpu().numpy()
-        verified = bool(np.array_equal(oo_o, oo_g) and np.array_equal(ids_o, ids_g))
-        if not verified:
-            raise SystemExit("PARITY FAILURE: GPU ids differ from the oracle")
+        for _ in range(args.warmup):
+            step()
+        sync()
+        batch.check_err()
+        tile_ms = []
+        if world > 1:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            tile_ms.append(ctx.last_timing()[0])  # HIP events around k_tiles on the launch stream
+        sync()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        total_bytes, total_ids = batch.n_bytes, batch.n_ids()
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+            tb = torch.tensor([batch.n_bytes, total_ids], dtype=torch.int64, device=cdev)
+            dist.all_reduce(tb)
+            total_bytes, total_ids = int(tb[0].item()), int(tb[1].item())
+        verified = None
+        if not args.no_verify:
+            from oracle import oracle as O
+            orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
+            verified = batch.verify(orc, data, offs, cores)
+        return dict(batch=batch, data=data, offs=offs, elapsed=elapsed, total_bytes=total_bytes, total_ids=total_ids,
+                    tile_ms=sum(tile_ms) / len(tile_ms), verified=verified, t_gen=t_gen)
+
+    # ---- weak: the whole corpus on every rank ------------------------------------------------------------
+    modes = {}
+    if args.scaling == "weak" or world > 1:
+        modes["weak"] = run_mode(rank * n_corpus, n_corpus)
+    # ---- strong (BASELINE config 4): ONE corpus, N byte-balanced contiguous shards -------------------------
+    if args.scaling == "strong" or world > 1:
+        if world == 1:
+            modes["strong"] = modes.get("weak") or run_mode(0, n_corpus)
+        else:
+            if "weak" in modes:  # free the weak batch's buffers first
+                modes["weak"].pop("batch"); modes["weak"].pop("data"); modes["weak"].pop("offs")
+                torch.cuda.empty_cache()
+            lens = synth.lengths(args.corpus, n_corpus, threads=gen_threads)  # lengths only: no rank holds the corpus
+            offs_all = np.zeros(n_corpus + 1, dtype=np.int64)
+            np.cumsum(lens, out=offs_all[1:])
+            first, count = sharding.shard_by_bytes(offs_all, world)[rank]
+            modes["strong"] = run_mode(first, count)
+            modes["strong"]["shard"] = (int(first), int(count))
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = total_bytes * args.steps / elapsed / 1e9
-        t_tile = sum(tile_ms) / len(tile_ms) / 1e3
-        b_alg = n_bytes + 8 * (n_docs + 1) + 4 * n_ids + 4 * n_docs
+        main_mode = args.scaling if args.scaling in modes else "weak"
+        m = modes[main_mode]
+
+        def mode_line(mm):
+            return {"value": round(mm["total_bytes"] * args.steps / mm["elapsed"] / 1e9, 3), "unit": "GB/s",
+                    "ms_per_step": round(mm["elapsed"] / args.steps * 1e3, 4), "total_bytes": mm["total_bytes"],
+                    "total_ids": mm["total_ids"], "verified_vs_oracle": mm["verified"]}
+
+        ml = mode_line(m)
+        t_tile = m["tile_ms"] / 1e3
+        # algorithmic bytes of THIS RANK's k_tiles launch (SURVEY 8d): input + offsets read, ids + per-doc counts written
+        rb = modes[main_mode]
+        r_bytes = rb["batch"].n_bytes if "batch" in rb else rb["total_bytes"] // world
+        r_docs = rb["batch"].n_docs if "batch" in rb else n_corpus
+        r_ids = rb["batch"].n_ids() if "batch" in rb else rb["total_ids"] // world
+        b_alg = r_bytes + 8 * (r_docs + 1) + 4 * r_ids + 4 * r_docs
         achieved = b_alg / t_tile / 1e9
-        traffic, traffic_src = committed_traffic(n_bytes)
+        tr, tr_src = committed_profile(r_bytes, "traffic")
+        iss, iss_src = committed_profile(r_bytes, "issue")
+        shape = "mixed UTF-8" if args.corpus == "C3" else "ASCII" if args.corpus == "C2" else "Hungarian-like UTF-8"
+        vdesc = "VG (GPT-2 shape, 50257 entries)" if args.vocab == "VG" else \
+                "VL (Llama/SentencePiece shape, 32000 entries, prefix U+2581, is_byte_encoder=False)"
         line = {
             "metric": "GB/s input text encoded (GPT-2 vocab) at 1/2/4/8 GPUs; bit-exact ids",
-            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.corpus}: {n_docs} synthetic docs per GPU "
-                                   f"({n_bytes / 1e6:.1f} MB, mean {n_bytes / n_docs:.0f} B, "
-                                   f"{'mixed UTF-8' if args.corpus != 'C2' else 'ASCII'}), "
-                                   "vocab VG (GPT-2 shape, 50257 entries)"
+            "value": ml["value"], "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ml["ms_per_step"], "higher_is_better": True,
+            "scaling": main_mode, "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.corpus}: {n_corpus} synthetic docs "
+                                   f"{'per GPU' if main_mode == 'weak' else 'in all, cut into byte-balanced shards'} "
+                                   f"({r_bytes / 1e6:.1f} MB on rank 0, mean {r_bytes / max(r_docs, 1):.0f} B, {shape}), "
+                                   f"vocab {vdesc}"
                                    f"{', id-keyed merge path (merges file)' if args.merges else ''}, "
                                    "device-resident packed I/O",
-                       "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "ids_per_gpu": n_ids,
+                       "docs_per_gpu": r_docs, "bytes_per_gpu": r_bytes, "ids_per_gpu": r_ids,
                        "parallelism": f"documents sharded over {world} GPU(s), all-gather of id totals"},
             "roofline": {"bound": "hbm", "kernel": "k_tiles", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": round(t_tile * 1e3, 4),
-                         "algorithmic_bytes": b_alg},
-            "verified_vs_oracle": verified,
-            "gen_s": round(t_gen, 2),
+                         "traffic": tr["traffic_bytes_per_launch"] if tr else None, "traffic_source": tr_src,
+                         "kernel_ms": round(t_tile * 1e3, 4), "algorithmic_bytes": b_alg},
+            "verified_vs_oracle": m["verified"],
+            "gen_s": round(m["t_gen"], 2),
         }
+        # The limit that binds: instruction issue.  VALU wave-instructions of one launch (committed PMC profile of this
+        # workload) x 4 cycles each, over the 1024 SIMDs, against the cycles this run's launch took at the profiled clock.
+        if iss:
+            valu = float(iss["valu_insts_per_launch"])
+            clk = float(iss["busy_cycles_per_launch"]) / (float(iss["kernel_ms_profiled"]) * 1e-3)  # cycles per second
+            cycles_now = clk * t_tile
+            line["roofline"]["issue"] = {
+                "bound": "valu_issue", "valu_wave_insts": valu, "salu_wave_insts": iss.get("salu_insts_per_launch"),
+                "lds_bank_conflict_frac": iss.get("lds_bank_conflict_frac"), "ta_busy_frac": iss.get("ta_busy_frac"),
+                "cycles": round(cycles_now), "peak_insts_per_cycle": N_SIMD / 4.0,
+                "frac": round(valu * 4.0 / (N_SIMD * cycles_now), 4), "frac_profiled": iss.get("valu_issue_frac"),
+                "source": iss_src,
+                "note": "a wave64 VALU instruction occupies one of the 1024 SIMDs for 4 cycles; frac = share of the launch's "
+                        "SIMD cycles spent issuing VALU work.  This, not HBM, is what bounds k_tiles"}
+        if world > 1:
+            line["weak"] = mode_line(modes["weak"])
+            line["strong"] = dict(mode_line(modes["strong"]),
+                                  workload=f"{args.corpus}: {n_corpus} docs in all, {world} byte-balanced shards "
+                                           "(BASELINE config 4)",
+                                  rank0_shard_docs=modes["strong"].get("shard", (0, n_corpus))[1])
+        if world == 1 and not args.no_extras and "batch" in m:
+            from oracle import oracle as O
+            orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp)
+            try:
+                line["end_to_end"] = end_to_end(ctx, orc, m["data"], m["offs"], vp, sp, kw, dev_index, cores, args.no_verify)
+            except SystemExit:
+                raise
+            except Exception as e:  # a measurement beside the metric must not lose the line
+                line["end_to_end"] = {"error": repr(e)}
+            m.pop("batch"); torch.cuda.empty_cache()
+            try:
+                line["secondary"] = secondary_runs(dev, dev_index, cores, args.no_verify)
+            except SystemExit:
+                raise
+            except Exception as e:
+                line["secondary"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(vp, sp, kw, args.corpus, min(args.cpu_docs, n_docs), cores, mp)
+            line["cpu_baseline"] = cpu_baseline(vp, sp, kw, args.corpus, min(args.cpu_docs, n_corpus), cores, mp)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -68,8 +68,7 @@ struct hutk_ctx {
     DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
-    DevBuf<uint4> d_word_keys, d_word_short;
-    DevBuf<uint32_t> d_word_syms;
+    DevBuf<WordSlot> d_word_tab;
     int64_t n_word_entries = 0;
     DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
     DevBuf<long long> w_prof;
@@ -79,7 +78,7 @@ struct hutk_ctx {
     // workspace
     DevBuf<uint32_t> w_run;
     DevBuf<int32_t> w_exc_tok;
-    DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
+    DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters, w_defer;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
     DevBuf<uint32_t> w_exc_long, w_exc_quad, w_exc_wave;
@@ -185,12 +184,10 @@ int upload_tables(hutk_ctx* c) {
     D.rank_is_sym = T.rank_is_sym;
     D.ident_ids = T.ident_ids;
     D.sym16 = T.sym16;
+    D.split_merge = getenv("HUTK_SPLIT_MERGE") && atoi(getenv("HUTK_SPLIT_MERGE")) ? 1 : 0;
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
-    D.word_keys = nullptr;
-    D.word_syms = nullptr;
+    D.word_tab = nullptr;
     D.word_mask = 0;
-    D.word_short = nullptr;
-    D.wordl_mask = 0;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
@@ -274,11 +271,12 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));
     HIP_TRY(c->w_exc_sym.reserve(exc_elems));
     HIP_TRY(c->w_exc_mrg.reserve(exc_elems));
-    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 6 + 8));
+    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + 8));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     HIP_TRY(c->w_counters.reserve(8));
     HIP_TRY(c->w_err.reserve(1));
+    if (tiles_defer(c->dt)) HIP_TRY(c->w_defer.reserve((size_t)n_tiles * DEFER_WORDS + 64));
     const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_long.reserve((size_t)cap_exc));
@@ -295,6 +293,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_exc_first = u + 3 * n_tiles;
     W.tile_nexc = u + 4 * n_tiles;
     W.exc_tiles = u + 5 * n_tiles;
+    W.tile_ndefer = u + 6 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
     W.scan_part = c->w_tile_i64.p + 2 * n_tiles + 2;
@@ -304,6 +303,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.exc_quad = c->w_exc_quad.p;
     W.exc_wave = c->w_exc_wave.p;
     W.counters = c->w_counters.p;
+    W.defer_mask = c->w_defer.p;
     W.cap_exc = cap_exc;
     W.pad_per_doc = (int32_t)pad;
     W.prof = nullptr;
@@ -321,9 +321,9 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_keys.release(); c->d_word_syms.release(); c->d_word_short.release();
+        c->d_word_tab.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
-        c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
+        c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release(); c->w_defer.release();
         c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
         c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
         c->dw_state.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
@@ -370,63 +370,33 @@ int build_word_table(hutk_ctx* c) {
         if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
             keep.push_back(i);
     if (keep.empty()) return HUTK_OK;
-    // two-choice cuckoo tables (hutk_internal.h); a word that cannot be placed is simply left out
+    // two-choice cuckoo table of 20-byte slots (hutk_device.h); a word that cannot be placed is simply left out
     std::vector<uint4> kk(keep.size());
-    std::vector<uint32_t> shortq, longq;
     for (size_t q = 0; q < keep.size(); q++) {
         const size_t i = keep[q];
         uint32_t k[4] = {0, 0, 0, 0};
         const size_t len = (size_t)(offs[i + 1] - offs[i]);
         for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
         kk[q] = make_uint4(k[0], k[1], k[2], k[3]);
-        (len <= 12 ? shortq : longq).push_back((uint32_t)q);
     }
+    uint32_t cap = 1024;
+    while (cap < keep.size() * 5 / 2 + 16) cap <<= 1;
+    std::vector<uint32_t> where, homeless;
+    auto hash_of = [&](uint32_t j) { const uint4 k = kk[j]; return word_hash(k.x, k.y, k.z, k.w); };
+    cuckoo_place(keep.size(), cap, [&](uint32_t j) { return hash_of(j) & (cap - 1); },
+                 [&](uint32_t j) { return word_slot2(hash_of(j), cap - 1); }, where, &homeless);
+    std::vector<WordSlot> slots(cap + 1, WordSlot{{0, 0, 0, 0}, 0});
     size_t placed = 0;
-    auto place = [&](const std::vector<uint32_t>& qs, uint32_t& cap, std::vector<uint32_t>& where) {
-        cap = 1024;
-        while (cap < qs.size() * 5 / 2 + 16) cap <<= 1;
-        std::vector<uint32_t> homeless;
-        cuckoo_place(qs.size(), cap,
-                     [&](uint32_t j) { const uint4 k = kk[qs[j]]; return word_hash(k.x, k.y, k.z, k.w); },
-                     [&](uint32_t j) { const uint4 k = kk[qs[j]]; return word_hash2(k.x, k.y, k.z, k.w); },
-                     where, &homeless);
-    };
-    if (!shortq.empty()) {
-        uint32_t cap;
-        std::vector<uint32_t> where;
-        place(shortq, cap, where);
-        std::vector<uint4> slots(cap + 1, make_uint4(0, 0, 0, 0));
-        for (size_t j = 0; j < shortq.size(); j++) {
-            if (where[j] == 0xFFFFFFFFu) continue;
-            const uint4 k = kk[shortq[j]];
-            slots[where[j]] = make_uint4(k.x, k.y, k.z, T.cand_sym[keep[shortq[j]]]);
-            placed++;
-        }
-        HIP_TRY(c->d_word_short.reserve(slots.size()));
-        HIP_TRY(hipMemcpy(c->d_word_short.p, slots.data(), slots.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        c->dt.word_short = c->d_word_short.p;
-        c->dt.word_mask = cap - 1;
+    for (size_t j = 0; j < keep.size(); j++) {
+        if (where[j] == 0xFFFFFFFFu) continue;
+        const uint4 k = kk[j];
+        slots[where[j]] = WordSlot{{k.x, k.y, k.z, k.w}, T.cand_sym[keep[j]]};
+        placed++;
     }
-    if (!longq.empty() && c->dt.word_mask) {
-        uint32_t cap;
-        std::vector<uint32_t> where;
-        place(longq, cap, where);
-        std::vector<uint4> keys(cap, make_uint4(0, 0, 0, 0));
-        std::vector<uint32_t> syms(cap, 0);
-        for (size_t j = 0; j < longq.size(); j++) {
-            if (where[j] == 0xFFFFFFFFu) continue;
-            keys[where[j]] = kk[longq[j]];
-            syms[where[j]] = T.cand_sym[keep[longq[j]]];
-            placed++;
-        }
-        HIP_TRY(c->d_word_keys.reserve(cap));
-        HIP_TRY(c->d_word_syms.reserve(cap));
-        HIP_TRY(hipMemcpy(c->d_word_keys.p, keys.data(), cap * sizeof(uint4), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_word_syms.p, syms.data(), cap * 4, hipMemcpyHostToDevice));
-        c->dt.word_keys = c->d_word_keys.p;
-        c->dt.word_syms = c->d_word_syms.p;
-        c->dt.wordl_mask = cap - 1;
-    }
+    HIP_TRY(c->d_word_tab.reserve(slots.size()));
+    HIP_TRY(hipMemcpy(c->d_word_tab.p, slots.data(), slots.size() * sizeof(WordSlot), hipMemcpyHostToDevice));
+    c->dt.word_tab = c->d_word_tab.p;
+    c->dt.word_mask = cap - 1;
     c->n_word_entries = (int64_t)placed;
     return HUTK_OK;
 }
@@ -600,6 +570,7 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     launch_tiles(c->dt, A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
+    launch_merge(c->dt, A, W, s);  // (before the exception kernels: it sets a tile's id count, they add to it)
     launch_exceptions(c->dt, A, W, s);
     launch_scan(A, W, s);
     launch_gather(c->dt, A, W, s);

@@ -23,11 +23,18 @@ constexpr int LANE_MAX_BYTES = 63;   // and its byte length (its end must be wit
 // prefix units / prefix-alone ids granted to document-first words (beyond that budget: exception path)
 constexpr int RUN_EXTRA = 64;
 constexpr int RUN_STRIDE = TILE_BYTES + 64 + RUN_EXTRA;
+// k_merge: a word that waits for it owns a stretch of its tile's run, one slot per unit; bit p of the tile's
+// DEFER_WORDS-dword bitmap marks the stretch that begins at slot p, unused slots of a stretch end up RUN_DEAD
+constexpr int DEFER_WORDS = (RUN_STRIDE + 31) / 32;
+constexpr uint32_t RUN_DEAD = 0xFFFEu;  // (16-bit symbols stay below 0xFFF0; 0xFFFF is the unit that is no symbol)
 constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units merge in LDS
 
 // per-position codes produced by the classifier (parser.c:24-183 restated as a
 // function of a +-3 byte neighbourhood)
 enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE = 4, C_WS = 5, C_BAD = 6 };
+
+// slot of the whole-word table: 16 key bytes as four little-endian dwords, then the symbol (20 bytes, dword aligned)
+struct WordSlot { uint32_t k[4]; uint32_t sym; };
 
 struct DevTables {
     const uint4* pair_buckets;  // two entries per bucket {w0, w1, w0, w1}, see hutk_internal.h
@@ -48,15 +55,15 @@ struct DevTables {
     // [b1 << 8 | b2], stored as uint16 when sym16 else uint32 (SYM_NONE when unranked)
     const void* bytepair;
     int32_t sym16;  // every symbol < 0xFFF0: LDS arrays hold 16-bit symbols
-    // whole-word tables: raw word bytes (zero padded) -> symbol of the one token the word encodes to; two-choice
-    // cuckoo tables, empty slot = all zero.  Words of 2..12 bytes: one 16-byte slot {bytes 0-3, 4-7, 8-11,
-    // symbol}, one load per candidate slot.  Words of 13..16 bytes (rare): keys and symbols in two arrays.
-    // word_mask == 0: no tables.
-    const uint4* word_short;
+    // 1: k_tiles leaves the merge loop to k_merge + k_compact (byte-encoder mode, 16-bit symbols, rank == symbol order
+    // only).  Slower on the benchmark's text (two kernels bound by table gathers one after the other, 146 against 175
+    // GB/s), faster where every word merges (81 against 68 GB/s on 17-31-letter random words): off unless asked for
+    int32_t split_merge;
+    // whole-word table: raw word bytes of 2..16 bytes (zero padded to 16) -> symbol of the one token the word encodes to.
+    // Two-choice cuckoo, 20-byte slots, an empty slot is all zero (a key's first bytes never are); slot 1 = hash & mask,
+    // slot 2 = word_slot2(hash, mask) (hutk_internal.h).  word_mask == 0: no table.
+    const WordSlot* word_tab;
     uint32_t word_mask;
-    const uint4* word_keys;
-    const uint32_t* word_syms;
-    uint32_t wordl_mask;
     // the word splitter as an automaton (hutk_classify.h, namespace dfa): dfa::TABLE_BYTES of transition table, then
     // the 256-byte byte-class table; the same for every vocabulary, staged in LDS by k_tiles
     const uint4* split_dfa;
@@ -94,6 +101,8 @@ struct Workspace {
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in k_exc (count: counters[5])
     uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
+    uint32_t* tile_ndefer;     // [n_tiles] words of the tile that k_merge encodes
+    uint32_t* defer_mask;      // [n_tiles * DEFER_WORDS] stretches of the run that k_merge fills in (see DEFER_WORDS)
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
     long long* prof;           // diagnostic: [n_tiles][10] clock64 stamps of k_tiles, or null
@@ -143,6 +152,8 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s);
 void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s);  // v[i] += *base; *base = v[n-1]
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
+void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);  // no-op unless tiles_defer(t)
+bool tiles_defer(const DevTables& t);  // k_tiles leaves the merge loop to k_merge for this context
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);

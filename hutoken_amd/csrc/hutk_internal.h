@@ -61,10 +61,13 @@ HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     x *= 0x9E3779B1u;
     return x ^ (x >> 15);
 }
-HUTK_HD uint32_t word_hash2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
-    uint32_t x = k3 ^ ((k0 << 11) | (k0 >> 21)) ^ ((k1 << 23) | (k1 >> 9)) ^ ((k2 << 17) | (k2 >> 15));
-    x *= 0x85EBCA6Bu;
-    return x ^ (x >> 13);
+// second candidate slot from the same hash: an odd multiple of its upper bits away from the first (never the same slot)
+HUTK_HD uint32_t word_slot2(uint32_t h, uint32_t mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((h & mask) ^ __umul24((h >> 15) | 1u, 0x5BD1u)) & mask;
+#else
+    return ((h & mask) ^ (((h >> 15) | 1u) * 0x5BD1u)) & mask;
+#endif
 }
 
 // Two-choice cuckoo placement of n keys into `cap` (power of two) single-entry slots.  h1/h2 give the two

@@ -332,7 +332,7 @@ struct TileLds {
     uint32_t arena_used, extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
 };
 
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
@@ -353,6 +353,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #endif
     // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
     constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
+    // ... and then the merge loop is not run here at all: a word that needs it RESERVES one slot per unit in the
+    // tile's run, leaves its start and unit count in the first two, and k_merge fills the slots in (see there)
+    constexpr bool DEFER = FAST && SPLIT;
+    static_assert(FAST || !SPLIT, "k_merge is the short form of the merge loop");
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
 #if HUTK_POOL_SORT
@@ -580,20 +584,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 //   byte mode: symbol of the first byte (all a one-byte word needs)
                 //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
                 //   encodes to; two-choice cuckoo tables, entries verified by this pipeline at context creation;
-                //   2..12-byte words need one 16-byte load per candidate slot
+                //   one table for words of 2..16 bytes, 20-byte slots {16 key bytes, symbol}
                 const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
                 uint32_t k0, k1, k2, k3;
                 {
                     const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
                     const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
                     const uint32_t q0 = sw[0], q1 = sw[1], q2 = sw[2], q3 = sw[3], q4 = sw[4];
-                    k0 = q0; k1 = q1; k2 = q2; k3 = q3;
-                    if (o8) {
-                        k0 = funnel_r(q1, q0, o8);
-                        k1 = funnel_r(q2, q1, o8);
-                        k2 = funnel_r(q3, q2, o8);
-                        k3 = funnel_r(q4, q3, o8);
-                    }
+                    k0 = funnel_r(q1, q0, o8);  // (a shift of 0 returns the low word)
+                    k1 = funnel_r(q2, q1, o8);
+                    k2 = funnel_r(q3, q2, o8);
+                    k3 = funnel_r(q4, q3, o8);
                     // zero the bytes at and beyond nb (branch-free: two 64-bit masks; nb > 16 is never probed)
                     const uint64_t mlo = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
                     const uint64_t mhi = nb <= 8 ? 0ull : nb >= 16 ? ~0ull : ((1ull << (8 * (nb - 8))) - 1ull);
@@ -602,38 +603,23 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     k2 &= (uint32_t)mhi;
                     k3 &= (uint32_t)(mhi >> 32);
                 }
-                const bool probe_s = probe && nb <= 12, probe_l = probe && nb > 12;
-                const uint32_t h1 = probe_s ? word_hash(k0, k1, k2, 0u) & T.word_mask : 0u;
-                const uint32_t h2 = probe_s ? word_hash2(k0, k1, k2, 0u) & T.word_mask : 0u;
-                uint4 s1 = make_uint4(0, 0, 0, 0), s2 = s1, key1 = s1, key2 = s1;
-                uint32_t isym = 0, sym1 = 0, sym2 = 0;
+                const uint32_t wh = word_hash(k0, k1, k2, k3);
+                const uint32_t h1 = probe ? wh & T.word_mask : 0u;
+                const uint32_t h2 = probe ? word_slot2(wh, T.word_mask) : 0u;
+                WordSlot s1{}, s2{};
+                uint32_t isym = 0;
                 if (T.word_mask) {  // uniform
-                    s1 = T.word_short[h1];
-                    s2 = T.word_short[h2];
-                }
-                const bool any_long = T.wordl_mask && __any(probe_l);  // a word of 13..16 bytes in this round
-                if (any_long) {
-                    const uint32_t g1 = probe_l ? word_hash(k0, k1, k2, k3) & T.wordl_mask : 0u;
-                    const uint32_t g2 = probe_l ? word_hash2(k0, k1, k2, k3) & T.wordl_mask : 0u;
-                    key1 = T.word_keys[g1];
-                    key2 = T.word_keys[g2];
-                    sym1 = T.word_syms[g1];
-                    sym2 = T.word_syms[g2];
+                    s1 = T.word_tab[h1];
+                    s2 = T.word_tab[h2];
                 }
                 if (BYTE_MODE) isym = T.item_sym[b0];
                 bool done = false;
-                if (probe_s) {
-                    // bitwise on purpose: with && the compiler fetches .x first and the rest only on a match
-                    const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2)) == 0;
-                    const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2)) == 0;
+                if (probe) {
+                    // bitwise on purpose: with && the compiler fetches one word first and the rest only on a match
+                    const bool hit1 = ((s1.k[0] ^ k0) | (s1.k[1] ^ k1) | (s1.k[2] ^ k2) | (s1.k[3] ^ k3)) == 0;
+                    const bool hit2 = ((s2.k[0] ^ k0) | (s2.k[1] ^ k1) | (s2.k[2] ^ k2) | (s2.k[3] ^ k3)) == 0;
                     done = hit1 || hit2;
-                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? s1.w : s2.w);
-                }
-                if (probe_l) {
-                    const bool hit1 = ((key1.x ^ k0) | (key1.y ^ k1) | (key1.z ^ k2) | (key1.w ^ k3)) == 0;
-                    const bool hit2 = ((key2.x ^ k0) | (key2.y ^ k1) | (key2.z ^ k2) | (key2.w ^ k3)) == 0;
-                    done = hit1 || hit2;
-                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? sym1 : sym2);
+                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? s1.sym : s2.sym);
                 }
                 int n = 0;
                 SymT* Sdst = S + ws;
@@ -711,6 +697,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_ABLATE_MERGE
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
 #endif
+    if constexpr (!DEFER)
     for (;;) {
 #if HUTK_POOL_SORT
         // The pool is SORTED by unit count, longest words first (a counting sort: histogram, scan, cursors), so that
@@ -1054,11 +1041,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
         return x;
     };
-    uint32_t mine = (uint32_t)__popc(live16) + extra_ids(lane, own) + ((uint32_t)__popc(exc16) << 16);
+    // DEFER: a word that waits for k_merge reserves one slot per unit (its start bit counts the first)
+    const uint32_t defer16 = DEFER ? reinterpret_cast<const uint16_t*>(mergem)[lane] : 0u;
+    auto defer_extra = [&](int lr, uint32_t starts) -> uint32_t {
+        uint32_t x = 0;
+        if (DEFER)
+            for (uint32_t m = starts; m; m &= m - 1) x += (uint32_t)word_units(me, 16 * lr + __builtin_ctz(m)) - 1u;
+        return x;
+    };
+    // one scan for three counts: ids (bits 0-10, at most RUN_STRIDE), exception words (11-20), words left to k_merge (21-30)
+    uint32_t mine = (uint32_t)__popc(live16) + defer_extra(lane, defer16) + extra_ids(lane, own) +
+                    ((uint32_t)__popc(exc16) << 11) + ((uint32_t)__popc(defer16) << 21);
     uint32_t total;
-    uint32_t run = wave_excl_scan(mine, lane, &total);  // low 16: ids, high 16: exception words before me
-    lanepref[lane] = (uint16_t)run;
-    const uint32_t n_dense = total & 0xFFFFu, n_exc = total >> 16;
+    uint32_t run = wave_excl_scan(mine, lane, &total);
+    lanepref[lane] = (uint16_t)(run & 0x7FFu);
+    const uint32_t n_dense = total & 0x7FFu, n_exc = (total >> 11) & 0x3FFu;
+    static_assert(RUN_STRIDE < 2048 && TILE_BYTES < 1024, "count fields");
     uint32_t exc_first = 0;
     if (lane == 0) {
         if (n_exc) {
@@ -1075,6 +1073,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         W.tile_run_start[tile] = 0;
         W.tile_exc_first[tile] = exc_first;
         W.tile_nexc[tile] = n_exc;
+        if (DEFER) W.tile_ndefer[tile] = total >> 21;
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
@@ -1086,7 +1085,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     constexpr uint32_t STAGE_CAP = (uint32_t)(sizeof(me.sb) / sizeof(SymT));
     const bool staged = BYTE_MODE && HUTK_STAGE_RUN && n_dense <= STAGE_CAP;  // the same for the whole wavefront
     auto emit_run = [&](SymT* dst) {
-        uint32_t pos = run & 0xFFFFu, eidx = run >> 16;
+        uint32_t pos = run & 0x7FFu, eidx = (run >> 11) & 0x3FFu;
         uint32_t ev = live16 | exc16;
         if (PREFIXED && T.has_prefix) ev |= own;  // arena words have no live bit of their own
         for (; ev; ev &= ev - 1) {
@@ -1123,9 +1122,22 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const uint32_t na = alone_ids(ws);
                 for (uint32_t i = 0; i < na; i++) dst[pos++] = Sym<SymT>::narrow(T.prefix_alone_syms[i]);
             }
+            if (DEFER && ((defer16 >> j) & 1u)) {
+                // reserved stretch: {word start, unit count} now, the word's symbols (then RUN_DEAD) from k_merge
+                const uint32_t n = (uint32_t)word_units(me, ws);
+                dst[pos] = (SymT)ws;
+                dst[pos + 1] = (SymT)n;
+                atomicOr(&docm[pos >> 5], 1u << (pos & 31));  // (docm is free in this mode: bitmap of the stretches' first slots)
+                pos += n;
+                continue;
+            }
             if ((live16 >> j) & 1u) dst[pos++] = S[ws];  // stores only: nothing here waits
         }
     };
+    if (DEFER) {
+        if (lane < DEFER_WORDS) docm[lane] = 0;
+        wave_sync();
+    }
     if (staged) {
         emit_run(reinterpret_cast<SymT*>(sb));
         wave_sync();
@@ -1134,6 +1146,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             reinterpret_cast<uint4*>(run_out)[v] = reinterpret_cast<const uint4*>(sb)[v];
     } else {
         emit_run(run_out);
+    }
+    if (DEFER) {
+        wave_sync();
+        if (lane < DEFER_WORDS) W.defer_mask[tile * DEFER_WORDS + lane] = docm[lane];
     }
     wave_sync();
     HUTK_STAMP(7);
@@ -1149,10 +1165,291 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         uint32_t before = lanepref[lr];
         before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(livem)[lr] & below);
         before += extra_ids(lr, wmask16[lr] & below);
+        before += defer_extra(lr, reinterpret_cast<const uint16_t*>(mergem)[lr] & below);
         W.doc_tile_pos[d] = before;
     }
     HUTK_STAMP(8);
     HUTK_STAMP(9);
+}
+
+// ------------------------------------------------------------------------
+// k_merge: THE MERGE LOOP (src/core.c:66-209; rule "leftmost pair of minimal rank", src/queue.c:152-199) for the words
+// k_tiles left to it (byte-encoder mode, 16-bit symbols, rank == symbol order).  Inside k_tiles the loop made every
+// wavefront of a workgroup wait for the workgroup's longest word -- two thirds of that kernel's time.  Here a workgroup
+// takes the words of MG_TILES consecutive tiles, SORTS them by unit count in LDS (counting sort) and merges them 64 at a
+// time, one word per lane, so that the lanes of a chunk need about the same number of trips; no tile state is held
+// while it runs, so many workgroups are resident and their memory round trips overlap.
+//   1. the tiles' stretch bitmaps -> a list of words {tile, slot, start, units}, sorted by units (longest first)
+//   2. per chunk of 64: symbols and initial pair results of a word from its bytes (HBM) through the (byte, next byte)
+//      table; then one merge per trip with packed keys (merged symbol << 5 | position), as in k_tiles' short form;
+//      the surviving symbols go to the word's stretch of the run, RUN_DEAD fills the rest
+//   3. per tile: the run is compacted in place (dead slots out), the tile's id count, the ids-before-document values
+//      and the positions of its exception words are corrected.  Everything downstream sees a dense run.
+// ------------------------------------------------------------------------
+#ifndef HUTK_MG_TILES
+#define HUTK_MG_TILES 8
+#endif
+constexpr int MG_TILES = HUTK_MG_TILES, MG_POOL = 512, MG_UNITS = LANE_MAX_UNITS;
+constexpr int MG_CHUNKS = (RUN_STRIDE + 63) / 64 + 1;
+static_assert(MG_TILES <= 32 && MG_POOL >= 480, "pool entries keep the tile in 5 bits; a tile's words fit the pool");
+
+// ONE WAVEFRONT per workgroup and per MG_TILES tiles: nothing in here waits for another wavefront (lanes exchange data
+// through LDS with wave_sync() only), so a long word delays its own wavefront and nobody else.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void k_merge(DevTables T, BatchArgs A, Workspace W) {
+    // Symbols S and pair results M of the lane's word: MG_ROWS units per lane, unit i at [i * 64 + lane].  A chunk that
+    // holds a word of more units is 32 words wide: lane l < 32 also owns column l + 32 for its units MG_ROWS.. (LDS is
+    // what limits the resident wavefronts here, and their number is what hides the lookups' round trips).
+    constexpr int MG_ROWS = 16;
+    static_assert(MG_UNITS <= 2 * MG_ROWS, "two columns hold the longest word");
+    __shared__ __attribute__((aligned(16))) uint16_t SM[2 * MG_ROWS * 64];
+    __shared__ uint32_t pool[MG_POOL];
+    __shared__ uint32_t hist[MG_UNITS + 1], rank[MG_UNITS + 1], start[MG_UNITS + 1];
+    uint32_t* const unsorted = reinterpret_cast<uint32_t*>(SM);  // (the list before it is sorted: S and M are idle then)
+    static_assert(sizeof(SM) >= MG_POOL * 4, "the unsorted list shares the symbol arrays");
+    const int lane = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * MG_TILES;
+    uint16_t* const run16 = reinterpret_cast<uint16_t*>(W.run);
+    constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+    uint16_t* const S = SM;
+    uint16_t* const M = SM + 64 * MG_ROWS;
+
+    // words per tile, one tile per lane
+    const uint32_t my_cnt = (lane < MG_TILES && tile0 + lane < A.n_tiles) ? W.tile_ndefer[tile0 + lane] : 0u;
+
+    // groups of tiles whose words fit the pool (nearly always all of them at once)
+    for (int tb = 0; tb < MG_TILES;) {
+        int te = tb;
+        uint32_t total = 0;
+        for (; te < MG_TILES; te++) {  // (a tile has at most 480 words)
+            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, te);
+            if (total + c > (uint32_t)MG_POOL) break;
+            total += c;
+        }
+        if (total) {
+            if (lane <= MG_UNITS) { hist[lane] = 0; rank[lane] = 0; }
+            wave_sync();
+            // 1. the words of tiles [tb, te): one bit per stretch in the tile's bitmap, {start, units} in its first two slots
+            uint32_t n_seen = 0;  // (entries go to the list in lane order, one ballot per step)
+            for (int i = tb * DEFER_WORDS + lane; i < (te * DEFER_WORDS + 63) / 64 * 64; i += 64) {
+                const int t = i / DEFER_WORDS, w = i - t * DEFER_WORDS;
+                uint32_t bits = 0;
+                if (i < te * DEFER_WORDS && tile0 + t < A.n_tiles) bits = W.defer_mask[(tile0 + t) * DEFER_WORDS + w];
+                uint32_t before;
+                {
+                    uint32_t tot;
+                    before = wave_excl_scan((uint32_t)__popc(bits), lane, &tot);
+                    before += n_seen;
+                    n_seen += tot;
+                }
+                const uint16_t* run = run16 + (tile0 + t) * RUN_STRIDE;
+                for (; bits; bits &= bits - 1, before++) {
+                    const uint32_t p = 32u * w + (uint32_t)__builtin_ctz(bits);
+                    uint32_t wn;  // {start, units}: two 16-bit slots read as one (2-byte aligned) dword
+                    __builtin_memcpy(&wn, run + p, 4);
+                    const uint32_t ws = wn & 0xFFFFu, n = wn >> 16;
+                    unsorted[before] = (uint32_t)t | (p << 5) | (ws << 16) | ((n - 1u) << 26);
+                    atomicAdd(&hist[n], 1u);
+                }
+            }
+            wave_sync();
+            {   // lane i <-> words of MG_UNITS - i units: first pool entry of that count, longest words first
+                uint32_t tot;
+                const uint32_t st = wave_excl_scan(lane < MG_UNITS ? hist[MG_UNITS - lane] : 0u, lane, &tot);
+                if (lane < MG_UNITS) start[MG_UNITS - lane] = st;
+            }
+            wave_sync();
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t e = unsorted[i], n = (e >> 26) + 1u;
+                pool[start[n] + atomicAdd(&rank[n], 1u)] = e;
+            }
+            wave_sync();  // (the unsorted list is dead now: S and M may be written)
+
+            // 2. chunks of 64 words (32 while the words have more than MG_ROWS units: the longest come first), one word per lane
+            for (uint32_t base = 0, width; base < total; base += width) {
+                width = (pool[base] >> 26) + 1u > (uint32_t)MG_ROWS ? 32u : 64u;
+                bool have = (uint32_t)lane < width && base + lane < total;
+                const uint32_t e = have ? pool[base + lane] : 0u;
+                const int64_t tile = tile0 + (e & 31u);
+                const uint32_t p = (e >> 5) & 2047u, ws = (e >> 16) & 1023u;
+                const int n = (int)(e >> 26) + 1;
+                // unit i of my word: row i % MG_ROWS of my column, or of column lane + 32 from unit MG_ROWS on
+                auto at = [&](int i) -> int { return ((i & (MG_ROWS - 1)) << 6) + lane + ((i >> 4) << 5); };
+                static_assert(MG_ROWS == 16, "at()");
+                auto Sw = [&](int i) -> uint16_t& { return S[at(i)]; };
+                auto Mw = [&](int i) -> uint16_t& { return M[at(i)]; };
+                auto scan_key = [&](uint32_t c) -> uint32_t {  // four candidates per step, their LDS reads in flight together
+                    uint32_t b = NOKEY;
+                    while (c) {
+                        const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
+                        const int i0 = __builtin_ctz(c);
+                        const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
+                                  i3 = c3 ? __builtin_ctz(c3) : i0;
+                        const uint32_t k0 = ((uint32_t)Mw(i0) << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw(i1) << 5) | (uint32_t)i1,
+                                       k2 = ((uint32_t)Mw(i2) << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw(i3) << 5) | (uint32_t)i3;
+                        b = min(min(b, k0), min(min(k1, k2), k3));
+                        c = c3 & (c3 - 1);
+                    }
+                    return b;
+                };
+                uint32_t live = 0, cand = 0, best = NOKEY;
+                if (have) {
+                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                    // eight units per step: three dwords of the word's bytes, two consecutive bytes = index of the
+                    // (byte, next byte) table, whose entry is {symbol of the byte, merged symbol of the pair}
+                    const int64_t g = tile * TILE_BYTES + ws;  // the word's first byte
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
+                    for (int i0 = 0; i0 < n; i0 += 8) {
+                        const int64_t a = (g + i0) & ~(int64_t)3;
+                        const int o8 = 8 * (int)((g + i0) & 3);
+                        uint32_t q[3];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const int64_t at = a + 4 * k;
+                            if (at + 4 <= A.n_bytes) {
+                                q[k] = *reinterpret_cast<const uint32_t*>(A.bytes + at);
+                            } else {  // the last bytes of the batch
+                                q[k] = 0;
+                                for (int b = 0; b < 4; b++)
+                                    if (at + b < A.n_bytes) q[k] |= (uint32_t)A.bytes[at + b] << (8 * b);
+                            }
+                        }
+                        const uint64_t lo = (uint64_t)funnel_r(q[1], q[0], o8) | ((uint64_t)funnel_r(q[2], q[1], o8) << 32);
+                        const uint32_t k2 = q[2] >> o8;  // its low byte is byte 8 of the stretch
+                        uint32_t en[8];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) en[j] = bp[(uint32_t)(lo >> (8 * j)) & 0xFFFFu];
+#pragma unroll
+                        for (int j = 4; j < 8; j++) en[j] = 0xFFFFFFFFu;
+                        if (i0 + 4 < n) {  // (the table is 256 KB of L2: a lookup that nobody needs still costs an address cycle)
+#pragma unroll
+                            for (int j = 4; j < 8; j++) {
+                                const uint32_t idx = j < 7 ? (uint32_t)(lo >> (8 * j)) & 0xFFFFu
+                                                           : ((uint32_t)(lo >> 56) | ((k2 & 0xFFu) << 8));
+                                en[j] = bp[idx];
+                            }
+                        }
+                        uint32_t cb = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {  // (rows beyond the word but inside the lane's column: stored all the same)
+                            Sw(i0 + j) = (uint16_t)en[j];
+                            Mw(i0 + j) = (uint16_t)(en[j] >> 16);
+                            cb |= (en[j] < 0xFFFF0000u ? 1u : 0u) << j;
+                        }
+                        cand |= cb << i0;
+                    }
+                    cand &= (1u << (n - 1)) - 1u;  // the last unit has no next one (n >= 2)
+                    best = scan_key(cand);
+                }
+                for (;;) {  // one merge per trip and lane
+                    if (!__any(have && best != NOKEY)) break;
+                    if (have && best != NOKEY) {
+                        const int pp = (int)(best & 31u);
+                        const uint32_t merged = best >> 5;
+                        const uint32_t above = live & ~((2u << pp) - 1u);  // not empty: bit pp of cand was set
+                        const int q = __builtin_ctz(above);                // the unit the merge consumes
+                        Sw(pp) = (uint16_t)merged;
+                        live &= ~(1u << q);
+                        const uint32_t right = above & (above - 1u);     // live units after q
+                        const uint32_t left = live & ((1u << pp) - 1u);  // live units before pp: none iff pp == 0
+                        const int q2 = right ? __builtin_ctz(right) : 0;
+                        const int p0 = 31 - __builtin_clz(left | 1u);    // == pp when there is none
+                        const uint32_t sr = Sw(q2), sl = Sw(p0);         // (read and looked up even when absent)
+                        const PairProbe s1 = pair_issue(T, merged, sr);
+                        const PairProbe s2 = pair_issue(T, sl, merged);
+                        cand &= ~((1u << q) | (1u << pp) | (1u << p0));
+                        best = scan_key(cand);
+                        uint32_t mr = pair_resolve(T, s1, merged, sr), ml = pair_resolve(T, s2, sl, merged);
+                        mr = right ? mr : SYM_NONE;
+                        ml = left ? ml : SYM_NONE;
+                        Mw(p0) = (uint16_t)ml;  // first: without a left neighbour p0 == pp
+                        Mw(pp) = (uint16_t)mr;
+                        const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
+                        cand |= ((hr ? 1u : 0u) << pp) | ((hl ? 1u : 0u) << p0);
+                        const uint32_t kr = hr ? ((mr << 5) | (uint32_t)pp) : NOKEY;
+                        const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
+                        best = min(best, min(kr, kl));
+                    }
+                }
+                if (have) {  // the survivors in order, then RUN_DEAD up to the end of the stretch; two slots per store
+                    uint16_t* out = run16 + tile * RUN_STRIDE + p;
+                    uint32_t c = live;
+                    auto next_out = [&]() -> uint32_t {
+                        if (!c) return RUN_DEAD;
+                        const uint32_t v = Sw(__builtin_ctz(c));
+                        c &= c - 1;
+                        return v;
+                    };
+                    int k = 0;
+                    if (p & 1u) out[k++] = (uint16_t)next_out();  // up to the next dword boundary
+                    for (; k + 2 <= n; k += 2) {
+                        const uint32_t lo = next_out(), hi = next_out();
+                        *reinterpret_cast<uint32_t*>(out + k) = lo | (hi << 16);
+                    }
+                    if (k < n) out[k] = (uint16_t)next_out();
+                }
+                wave_sync();
+            }
+        }
+        tb = te > tb ? te : tb + 1;
+    }
+}
+
+// ------------------------------------------------------------------------
+// k_compact: after k_merge a tile's run has RUN_DEAD slots where words merged.  One wavefront per tile takes them out in
+// place and corrects what was counted in slots: the tile's id count, the ids-before-document values of the documents
+// that start in it and the positions of its exception words.  Everything downstream sees a dense run.
+// ------------------------------------------------------------------------
+constexpr int CP_WAVES = 4;
+__global__ __launch_bounds__(64 * CP_WAVES) void k_compact(BatchArgs A, Workspace W) {
+    __shared__ unsigned long long s_bal[CP_WAVES][MG_CHUNKS];  // live slots of a 64-slot piece ...
+    __shared__ uint32_t s_cum[CP_WAVES][MG_CHUNKS];            // ... and the live slots before it
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * CP_WAVES + wv;
+    if (tile >= A.n_tiles || W.tile_ndefer[tile] == 0) return;
+    uint16_t* run = reinterpret_cast<uint16_t*>(W.run) + tile * RUN_STRIDE;
+    const uint32_t dense = W.tile_dense[tile];  // slots used, stretches included
+    uint32_t outn = 0;
+    int c = 0;
+    constexpr int CP_UNROLL = 8;  // pieces of 64 slots read together (a tile has ~400 slots): one round trip, not eight
+    for (uint32_t kb = 0; kb < dense; kb += 64 * CP_UNROLL) {
+        uint16_t v[CP_UNROLL];
+#pragma unroll
+        for (int j = 0; j < CP_UNROLL; j++) {
+            const uint32_t k = kb + 64 * j + lane;
+            v[j] = k < dense ? run[k] : (uint16_t)RUN_DEAD;
+        }
+#pragma unroll
+        for (int j = 0; j < CP_UNROLL; j++) {
+            if (kb + 64 * j >= dense) break;
+            const bool alive = v[j] != (uint16_t)RUN_DEAD;
+            const unsigned long long bal = __ballot(alive);
+            if (alive) run[outn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = v[j];  // never ahead of what is still to be read
+            if (lane == 0) { s_bal[wv][c] = bal; s_cum[wv][c] = outn; }
+            outn += (uint32_t)__popcll(bal);
+            c++;
+        }
+    }
+    if (lane == 0) { s_bal[wv][c] = 0; s_cum[wv][c] = outn; }
+    wave_sync();
+    auto live_before = [&](uint32_t pos) -> uint32_t {  // live slots before slot pos (pos <= dense)
+        const uint32_t cc = pos >> 6;
+        return s_cum[wv][cc] + (uint32_t)__popcll(s_bal[wv][cc] & ((1ull << (pos & 63u)) - 1ull));
+    };
+    if (lane == 0) { W.tile_dense[tile] = outn; W.tile_count[tile] = outn; }
+    const int64_t t0 = tile * TILE_BYTES;
+    const int64_t t_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
+    for (int64_t d = W.tile_first_doc[tile] + lane; d <= A.n_docs; d += 64) {
+        const int64_t o = A.offsets[d];
+        if (o >= t_end) break;
+        if (o < t0) continue;
+        W.doc_tile_pos[d] = live_before(W.doc_tile_pos[d]);
+    }
+    const uint32_t nexc = W.tile_nexc[tile];
+    for (uint32_t x = lane; x < nexc; x += 64) {
+        ExcRec* r = W.exc + W.tile_exc_first[tile] + x;
+        r->wpos = live_before(r->wpos);
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -2112,6 +2409,11 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), dim3(64 * WV), 0, s, \
                        t, a, w)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
+    if (tiles_defer(t)) {  // the merge loop in k_merge instead (DevTables::split_merge)
+        hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, true>),
+                           dim3((unsigned)(((a.n_tiles + TILE_WAVES - 1) / TILE_WAVES + 7) / 8 * 8)), dim3(64 * TILE_WAVES), 0, s, t, a, w);
+        return;
+    }
     switch (variant) {
         case 7: HUTK_LAUNCH(uint16_t, true, true, TILE_WAVES); break;
         case 6: HUTK_LAUNCH(uint16_t, true, false, TILE_WAVES); break;
@@ -2123,6 +2425,14 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
         default: HUTK_LAUNCH(uint32_t, false, false, TILE_WAVES); break;
     }
 #undef HUTK_LAUNCH
+}
+bool tiles_defer(const DevTables& t) {
+    return HUTK_FAST_MERGE && t.split_merge && t.sym16 && t.is_byte_encoder && t.rank_is_sym;
+}
+void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+    if (!tiles_defer(t)) return;
+    hipLaunchKernelGGL(k_merge, dim3((unsigned)((a.n_tiles + MG_TILES - 1) / MG_TILES)), dim3(64), 0, s, t, a, w);
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((a.n_tiles + CP_WAVES - 1) / CP_WAVES)), dim3(64 * CP_WAVES), 0, s, a, w);
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     // fixed grid; every wavefront pulls records until the device counter runs out

@@ -320,3 +320,31 @@ int64_t hutk_synth_corpus(int kind, uint64_t seed, int64_t first_doc, int64_t n_
 }
 
 void hutk_synth_free(void* p) { free(p); }
+
+/* Lengths only (bytes per document) of documents [first_doc, first_doc + n_docs): what a rank needs to find its
+ * byte-balanced shard of a corpus without holding the corpus (bench.py, strong scaling). */
+struct len_job { int kind; uint64_t seed; int64_t first, count; int64_t* lens; };
+static void* len_run(void* a) {
+    struct len_job* j = a;
+    uint8_t tmp[8192 + 256];
+    for (int64_t i = 0; i < j->count; i++) j->lens[i] = gen_doc(j->kind, j->seed, j->first + i, tmp);
+    return NULL;
+}
+int hutk_synth_lengths(int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int num_threads, int64_t* lens) {
+    pthread_once(&g_once, init_tables);
+    if (kind != 2 && kind != 3 && kind != 5) return -1;
+    if (num_threads < 1) num_threads = 1;
+    if (num_threads > 64) num_threads = 64;
+    struct len_job jobs[64];
+    pthread_t th[64];
+    int64_t per = (n_docs + num_threads - 1) / num_threads;
+    for (int t = 0; t < num_threads; t++) {
+        int64_t a = per * t, b = a + per;
+        if (a > n_docs) a = n_docs;
+        if (b > n_docs) b = n_docs;
+        jobs[t] = (struct len_job){kind, seed, first_doc + a, b - a, lens + a};
+        pthread_create(&th[t], NULL, len_run, &jobs[t]);
+    }
+    for (int t = 0; t < num_threads; t++) pthread_join(th[t], NULL);
+    return 0;
+}

@@ -24,6 +24,8 @@ def _load():
         L.hutk_synth_corpus.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int,
                                         C.POINTER(C.POINTER(C.c_uint8)), C.c_void_p]
         L.hutk_synth_free.argtypes = [C.c_void_p]
+        L.hutk_synth_lengths.restype = C.c_int
+        L.hutk_synth_lengths.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -47,6 +49,37 @@ def corpus(name, n_docs=None, first_doc=0, seed=None, threads=None):
     return data, offs
 
 
+def lengths(name, n_docs=None, first_doc=0, seed=None, threads=None):
+    """Byte lengths (int64[n_docs]) of documents [first_doc, first_doc+n_docs) without keeping their bytes."""
+    kind, dseed, dn = KINDS[name]
+    n_docs = dn if n_docs is None else int(n_docs)
+    out = np.zeros(max(n_docs, 1), dtype=np.int64)
+    rc = _load().hutk_synth_lengths(kind, dseed if seed is None else seed, first_doc, n_docs,
+                                    threads or min(16, os.cpu_count() or 1), out.ctypes.data)
+    if rc:
+        raise ValueError("unknown corpus")
+    return out[:n_docs]
+
+
 def docs_as_str(data, offs):
     b = data.tobytes()
     return [b[offs[i]:offs[i + 1]].decode("utf-8") for i in range(len(offs) - 1)]
+
+
+def random_words(lo, hi, n_docs, words_per_doc=20, seed=0x52574f52, lexicon=20000, alphabet=b"etaoinshrdlucmfw"):
+    """Texts OFF the vocabulary's distribution: documents of `words_per_doc` words drawn uniformly from a lexicon of
+    random-letter words of lo..hi letters, each followed by one space (hardly any is a vocabulary key, so every
+    word goes through the merge loop; beyond 32 units a word leaves the tile kernel for the exception kernels).
+    -> (uint8 array, int64 offsets[n_docs+1]); numpy's PCG64 with a fixed seed, identical on every host."""
+    rng = np.random.default_rng(seed + 1000 * lo + hi)
+    alpha = np.frombuffer(alphabet, dtype=np.uint8)
+    lens = rng.integers(lo, hi + 1, lexicon)
+    W = alpha[rng.integers(0, len(alpha), (lexicon, hi + 1))]
+    W[np.arange(lexicon), lens] = 0x20  # the separator right after the word
+    idx = rng.integers(0, lexicon, (n_docs, words_per_doc))
+    wl = (lens + 1)[idx]
+    mask = np.arange(hi + 1)[None, None, :] < wl[:, :, None]
+    data = W[idx][mask]
+    offs = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(wl.sum(axis=1), out=offs[1:])
+    return np.ascontiguousarray(data), offs

@@ -86,3 +86,21 @@ def test_full_size_without_the_whole_word_table(g, monkeypatch):
     ids, oo = encode_one_launch(ctx, d, o)
     check_against(g, ids, oo)
     ctx.close()
+
+
+@pytest.mark.parametrize("no_table", [False, True], ids=["table", "no-table"])
+@pytest.mark.parametrize("g", [g for g in g7_cases() if g["vocab"] == "VG"], ids=case_id)
+def test_full_size_with_the_split_merge_kernels(g, no_table, monkeypatch):
+    """HUTK_SPLIT_MERGE=1: k_tiles leaves the merge loop to k_merge (words sorted by unit count, one per lane) and
+    k_compact; the same ids.  Also without the whole-word table, i.e. with every word going that way."""
+    from hutoken_amd import _capi, data, synth
+    monkeypatch.setenv("HUTK_SPLIT_MERGE", "1")
+    if no_table:
+        monkeypatch.setenv("HUTK_NO_WORD_TABLE", "1")
+    vp, sp, kw = data.vocab_files(g["vocab"])
+    mp = data.merges_file(g["vocab"]) if g["merges"] else None
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], merges_path=mp)
+    d, o = synth.corpus(g["corpus"], g["n_docs"])
+    ids, oo = encode_one_launch(ctx, d, o)
+    check_against(g, ids, oo)
+    ctx.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counters of k_tiles for several library builds on ONE GPU box (gpurun, from the repo root):
 #   tools/pmc_ab.sh TAG CORPUS N_DOCS VOCAB lib1.so lib2.so ...
-# One counter set per run (rocprofv3 --pmc with --kernel-trace only); the per-dispatch means of the full-size
+# PMC_KERNEL=<substring> selects another kernel than k_tiles.  One counter set per run (rocprofv3 --pmc with --kernel-trace only); the per-dispatch means of the full-size
 # k_tiles launches go to gpurun_out/pmc_<TAG>.txt.
 set -o pipefail
 TAG=$1; CORPUS=$2; NDOCS=$3; VOCAB=$4; shift 4
@@ -31,7 +31,7 @@ for lib in sys.argv[2:]:
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-            rows = [r for r in csv.DictReader(open(f)) if "k_tiles" in r.get("Kernel_Name", "")]
+            rows = [r for r in csv.DictReader(open(f)) if os.environ.get("PMC_KERNEL", "k_tiles") in r.get("Kernel_Name", "")]
             full = max((int(r["Grid_Size"]) for r in rows), default=0)
             acc = defaultdict(list)
             for r in rows:

@@ -62,6 +62,7 @@ if trace:
 
 lines += ["## PMC counters (per full-size k_tiles dispatch, mean over the run's dispatches of the bench workload)", ""]
 pmc = {}
+pmc_ms = {}  # counter -> mean duration (ms) of the full-size k_tiles launches in the run that collected it
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
     if not files:
@@ -74,9 +75,19 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for r in rows:
         if int(r["Grid_Size"]) == full:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    ms = None
+    if kt:
+        kr = [r for r in csv.DictReader(open(kt[0])) if "k_tiles" in r["Kernel_Name"]]
+        gs = "Grid_Size" if kr and "Grid_Size" in kr[0] else "Grid_Size_X"
+        if kr:
+            fullk = max(int(r[gs]) for r in kr)
+            du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in kr if int(r[gs]) == fullk]
+            ms = sum(du) / len(du)
     for name, vals in acc.items():
         lines.append(f"- {name}: {sum(vals) / len(vals):.4g}  (n={len(vals)})")
         pmc[name] = sum(vals) / len(vals)
+        pmc_ms[name] = ms
 lines.append("")
 # HBM-side traffic of one k_tiles launch, corrected as MI355X_MICROARCH.md (HBM section) prescribes:
 # FETCH_SIZE and WRITE_SIZE are kilobytes at the L2's memory side (Infinity-Cache hits included); on
@@ -89,5 +100,24 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
           "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
     json.dump(tj, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     lines += [f"HBM-side traffic per k_tiles launch (corrected): {traffic / 1e9:.3f} GB", ""]
+# The limit that binds k_tiles: VALU issue.  A wave64 VALU instruction occupies one of the 1024 SIMDs for 4 cycles;
+# GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+    cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0
+    ij = {"tag": tag, "kernel": "k_tiles", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
+          "salu_insts_per_launch": pmc.get("SQ_INSTS_SALU"), "lds_insts_per_launch": pmc.get("SQ_INSTS_LDS"),
+          "busy_cycles_per_launch": cycles, "kernel_ms_profiled": pmc_ms.get("GRBM_GUI_ACTIVE"),
+          "valu_issue_frac": pmc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
+          "lds_bank_conflict_frac": (pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"])
+          if "SQ_LDS_BANK_CONFLICT" in pmc and pmc.get("SQ_LDS_IDX_ACTIVE") else None,
+          "ta_busy_frac": (pmc["TA_BUSY_avr"] / cycles) if "TA_BUSY_avr" in pmc else None,
+          "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
+    json.dump(ij, open(os.path.join(dst, f"{tag}_issue.json"), "w"), indent=1)
+    lines += [f"VALU issue: {ij['valu_insts_per_launch']:.4g} wave-instructions x 4 cycles / (1024 SIMDs x {cycles:.4g} cycles) = "
+              f"{ij['valu_issue_frac']:.3f} of the launch's SIMD cycles", ""]
+    if ij["lds_bank_conflict_frac"] is not None:
+        lines += [f"LDS bank conflicts: {ij['lds_bank_conflict_frac']:.3f} of the LDS-active cycles", ""]
+    if ij["ta_busy_frac"] is not None:
+        lines += [f"Texture-address units busy: {ij['ta_busy_frac']:.3f} of the launch", ""]
 open(os.path.join(dst, f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines))
 print("\n".join(lines))
