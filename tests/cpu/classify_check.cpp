@@ -1,6 +1,7 @@
 // classify_check.cpp -- host fuzz of hutk_classify.h (the device word splitter)
 // against the oracle's sequential splitter (oracle/hutk_oracle.c).  Built and run by
-// tests/test_classify_cpu.py.   usage: classify_check <n_cases> <seed>
+// tests/test_classify_cpu.py.   usage: classify_check <n_cases> <seed> [mode]
+//                                        classify_check --texts   (hex text per stdin line -> its word starts by every form)
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,54 @@ static const char* PIECES[] = {
     "\xf0\x80\x80\x80", "\xf0\x80\x80\xa0", "\xf0\x80\x81\xa1", "\xf0\x8f\xbf\xbf", "\xc3\xc3", "\xe6\x20",
     "word", "Hello", "\xc3\xa1rv\xc3\xadzt\xc5\xb1r\xc5\x91"};
 
+// word starts of one document by the three forms of the device splitter, 16 positions per call as the kernel does
+static void starts_of(const std::vector<uint8_t>& text, const uint16_t* dfa_table, const uint8_t* dfa_lut,
+                      std::vector<uint32_t> out[3]) {
+    const size_t n = text.size();
+    for (size_t p0 = 0; p0 < n; p0 += 16) {
+        uint32_t d[8] = {0};
+        uint32_t dbits = 0;
+        for (int k = 0; k < 32; k++) {
+            const long p = (long)p0 - 8 + k;
+            if (p >= 0 && p < (long)n) d[k >> 2] |= (uint32_t)text[p] << (8 * (k & 3));
+            if (p == 0 || p == (long)n) dbits |= 1u << k;
+        }
+        bool ex_s = false, ex_d = false;
+        const uint32_t fe = hutk::classify16_exact(d, dbits);
+        uint32_t fs = hutk::classify16(d, dbits, &ex_s), fd = hutk::classify16_dfa(d, dbits, dfa_table, dfa_lut, &ex_d);
+        if (ex_s) fs = fe;  // (what the kernel does with a window the fast forms hand back)
+        if (ex_d) fd = fe;
+        for (int j = 0; j < 16 && p0 + j < n; j++) {
+            if ((fe >> j) & 1u) out[0].push_back((uint32_t)(p0 + j));
+            if ((fs >> j) & 1u) out[1].push_back((uint32_t)(p0 + j));
+            if ((fd >> j) & 1u) out[2].push_back((uint32_t)(p0 + j));
+        }
+    }
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "--texts")) {
+        static uint16_t tab[hutk::dfa::TABLE_BYTES / 2];
+        static uint8_t lut[256];
+        hutk::dfa::build(tab, lut);
+        char line[1 << 16];
+        while (fgets(line, sizeof line, stdin)) {
+            std::vector<uint8_t> text;
+            for (char* c = line; c[0] && c[1] && c[0] != '\n'; c += 2) {
+                unsigned v;
+                if (sscanf(c, "%2x", &v) != 1) break;
+                text.push_back((uint8_t)v);
+            }
+            std::vector<uint32_t> out[3];
+            starts_of(text, tab, lut, out);
+            for (int f = 0; f < 3; f++) {
+                printf("%s", f ? ";" : "");
+                for (size_t i = 0; i < out[f].size(); i++) printf("%s%u", i ? "," : "", out[f][i]);
+            }
+            printf("\n");
+        }
+        return 0;
+    }
     const long n_cases = argc > 1 ? atol(argv[1]) : 20000;
     rng_s = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1;
     const int mode = argc > 3 ? atoi(argv[3]) : 0;  // 1: no overlong pieces (keeps the fast paths in play); 2: byte soup

@@ -238,3 +238,39 @@ def test_chunked_host_path_equals_the_simple_one(vg_files, monkeypatch):
     assert rc == 0 and rc2 == 0
     assert st_c2[docs_mid] == 1 and oo_c2[docs_mid + 1] == oo_c2[docs_mid]
     assert np.array_equal(oo_s2, oo_c2) and np.array_equal(ids_s2, ids_c2) and np.array_equal(st_s2, st_c2)
+
+
+def test_g8_reference_fixtures(tmp_path):
+    """Loader quirk files, the reference parser's own test strings and texts with repeated pairs (tools/make_golden_g8.py:
+    outcomes of the compiled reference) through the product's loader and the GPU path."""
+    import sys
+    sys.path.insert(0, os.path.join(H.ROOT, "tools"))
+    import make_golden_g8 as G8  # only its seeded file builders
+    from test_reference_fixtures_cpu import REFUSED_BY_DESIGN
+    g = load("g8_reference_fixtures.json")
+    files = G8.quirk_files()
+    for case in g["loaders"]:
+        vocab, special, probes = files[case["name"]]
+        vp, sp = G8.write_case_files(str(tmp_path), case["name"], vocab, special)
+        if case["name"] in REFUSED_BY_DESIGN:
+            with pytest.raises(REFUSED_BY_DESIGN[case["name"]]):
+                ctx_for(vp, sp, None, True)
+            continue
+        if "error" in case:
+            with pytest.raises(Exception) as ei:
+                ctx_for(vp, sp, None, True)
+            assert [type(ei.value).__name__, str(ei.value)] == case["error"], case["name"]
+            continue
+        ctx = ctx_for(vp, sp, None, True)
+        assert encode_texts(ctx, probes) == case["ids"], case["name"]
+        ctx.close()
+    t = vf.bytes_to_unicode()
+    g1 = load("g1_handpicked.json")
+    raw = [bytes([b]) for b in vf.byte_token_order()] + [bytes.fromhex(m) for m in g1["byte_vocab"]["merges_hex"]]
+    vp, sp = H.write_vocab(tmp_path, "g8t", [(vf.encode_visible(tok, t), i) for i, tok in enumerate(raw)],
+                           vf.gpt2_special_mapping())
+    ctx = ctx_for(vp, sp, None, True)
+    cases = g["ties"]  # the parser's 28 strings are among them: wrong word boundaries would show as wrong ids
+    assert encode_texts(ctx, [c["text"] for c in cases]) == [c["ids"] for c in cases]
+    for c in cases:
+        assert ctx.encode_one(c["text"].encode("utf-8"))[0] == c["ids"]
