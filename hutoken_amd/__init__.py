@@ -53,12 +53,17 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
             or not (merges_file_path is None or isinstance(merges_file_path, str)) \
             or not isinstance(special_token_id, int):
         raise TypeError(_BAD_INIT_ARGS)
-    if pattern is not None:
-        raise RuntimeError("hutoken_amd: the regex `pattern` pre-token path (core.c:350-360) is outside "
-                           "the MI355X encode path; initialise with pattern=None")
     # merges_file_path: the id-keyed merge path (lib.c:573-663, core.c:211-337) on the same kernels
     new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device,
                         merges_path=merges_file_path)
+    if pattern is not None:
+        # the regex pre-token path (core.c:350-360): libc's regexec finds the words on the host, pretokenizer and
+        # merge loop run on the GPU
+        try:
+            new.set_pattern(pattern)
+        except Exception:
+            new.close()
+            raise
     old, _ctx = _ctx, new
     if old is not None:
         old.close()

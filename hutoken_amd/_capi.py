@@ -17,7 +17,7 @@ DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
 
 # every symbol include/hutoken_amd.h declares
 EXPORTS = [
-    "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
+    "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_ctx_set_pattern", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
@@ -71,6 +71,8 @@ def load(build_if_missing=True):
     L.hutk_ctx_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, i32]
     L.hutk_ctx_create_merges.restype = i32
     L.hutk_ctx_create_merges.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]
+    L.hutk_ctx_set_pattern.restype = i32
+    L.hutk_ctx_set_pattern.argtypes = [vp, C.c_char_p]
     L.hutk_uses_merges.restype = i32
     L.hutk_uses_merges.argtypes = [vp]
     L.hutk_decode_batch.restype = i32
@@ -171,6 +173,10 @@ class Context:
                                       None if merges_path is None else os.fsencode(merges_path), device)
         raise_for(rc)
         self._h = h
+
+    def set_pattern(self, pattern):
+        """The regex pre-token path (initialize's `pattern`, a POSIX ERE); None: the hand-written splitter."""
+        raise_for(load().hutk_ctx_set_pattern(self._h, None if pattern is None else pattern.encode("utf-8")))
 
     @property
     def uses_merges(self):

@@ -5,12 +5,16 @@
 // HIP kernels of hutk_kernels.hip or fails with HUTK_E_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <regex.h>
+
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hutk_classify.h"
@@ -73,6 +77,9 @@ struct hutk_ctx {
     DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
     DevBuf<long long> w_prof;
     bool profile = false;
+    // regex pre-token path: the pattern of initialize() (empty: the hand-written splitter) and the bitmaps of a batch
+    std::string pattern;
+    DevBuf<uint32_t> w_wbits, w_gbits;
     DevTables dt{};
 
     // workspace
@@ -321,7 +328,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_tab.release();
+        c->d_word_tab.release(); c->w_wbits.release(); c->w_gbits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release(); c->w_defer.release();
         c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
@@ -521,10 +528,27 @@ int hutk_debug_profile_read(hutk_ctx* c, int64_t n_tiles, double* out10) {
     return HUTK_OK;
 }
 
+static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
+                              int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap, int64_t* d_out_offsets,
+                              int32_t* d_status, int32_t* d_err, void* hip_stream, const uint32_t* d_word_bits,
+                              const uint32_t* d_gap_bits);
+
 int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets,
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap,
                              int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err,
                              void* hip_stream) {
+    if (c && !c->pattern.empty())
+        return set_err(HUTK_E_UNSUPPORTED,
+                       "a context with a regex pattern splits on the host (libc regexec): give it host buffers "
+                       "(hutk_encode_batch)");
+    return encode_device_impl(c, d_bytes, d_offsets, n_docs, n_bytes, d_ids_out, ids_cap, d_out_offsets, d_status, d_err,
+                              hip_stream, nullptr, nullptr);
+}
+
+static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
+                              int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap, int64_t* d_out_offsets,
+                              int32_t* d_status, int32_t* d_err, void* hip_stream, const uint32_t* d_word_bits,
+                              const uint32_t* d_gap_bits) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
     if (n_docs < 0 || n_bytes < 0 || !d_offsets || !d_out_offsets || (n_bytes > 0 && (!d_bytes || !d_ids_out)))
@@ -550,6 +574,8 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
     A.out_offsets = d_out_offsets;
     A.status = d_status;
     A.err = d_err ? d_err : c->w_err.p;
+    A.word_bits = d_word_bits;
+    A.gap_bits = d_gap_bits;
 
     c->ev_valid = false;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
@@ -610,8 +636,89 @@ static int64_t pipe_chunk_bytes(int64_t n_bytes) {  // an eighth of the batch, 1
     return std::min(hi, std::max(lo, n_bytes / 8));
 }
 
+// Regex pre-token path (reference src/core.c:350-360, 372-378, 392-400, 498-500), host half.  The reference compiles the
+// pattern (POSIX ERE) for every encode() call and takes, again and again, the LEFTMOST match at or after its cursor: the
+// match is a word, what lies before it is dropped, an empty match moves the cursor one byte on (or ends the document at
+// the end of the text).  This is libc's regexec in the process's locale, so it stays on the host -- with the same libc
+// calls -- and yields two bitmaps over the batch's bytes: where a word or a dropped stretch begins, and which of those
+// are dropped stretches.  Pretokenizer and merge loop then run on the GPU as for the hand-written splitter.
+// A word over the reference's limit (core.c:402-407) ends its document: the rest becomes a dropped stretch.
+static int regex_bitmaps(const std::string& pattern, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                         std::vector<uint32_t>& wbits, std::vector<uint32_t>& gbits, std::vector<uint8_t>& too_large) {
+    const int64_t n_bytes = offsets[n_docs];
+    const size_t n_words = (size_t)(n_bytes / 32 + 40);  // (a tile reads the bits of its whole 1024-position window)
+    wbits.assign(n_words, 0u);
+    gbits.assign(n_words, 0u);
+    too_large.assign((size_t)(n_docs ? n_docs : 1), 0);
+    auto set_bit = [](std::vector<uint32_t>& v, int64_t p) {
+        __atomic_fetch_or(&v[(size_t)(p >> 5)], 1u << (p & 31), __ATOMIC_RELAXED);
+    };
+    set_bit(wbits, n_bytes);  // the end of the data closes the last word
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt ? nt : 1u, 64u));
+    if ((int64_t)nt > n_docs) nt = (unsigned)std::max<int64_t>(1, n_docs);
+    std::atomic<int> failed{0};
+    auto work = [&](unsigned t) {
+        regex_t re;  // one compiled pattern per thread: glibc serialises regexec() on a shared regex_t
+        if (regcomp(&re, pattern.c_str(), REG_EXTENDED) != 0) { failed = 1; return; }
+        std::string z;
+        const int64_t d0 = n_docs * t / nt, d1 = n_docs * (t + 1) / nt;
+        for (int64_t d = d0; d < d1; d++) {
+            const int64_t base = offsets[d], len = offsets[d + 1] - base;
+            if (len <= 0) continue;
+            z.assign(reinterpret_cast<const char*>(bytes + base), (size_t)len);  // NUL-terminated copy
+            int64_t pos = 0, covered = 0;
+            auto gap_to = [&](int64_t upto) {  // [covered, upto) belongs to no word
+                if (upto > covered) { set_bit(wbits, base + covered); set_bit(gbits, base + covered); }
+            };
+            while (pos < len) {
+                regmatch_t m;
+                if (regexec(&re, z.c_str() + pos, 1, &m, 0) != 0) break;
+                const int64_t ws = pos + m.rm_so, wl = m.rm_eo - m.rm_so;
+                if (wl == 0) {
+                    if (ws >= len) break;
+                    pos = ws + 1;
+                    continue;
+                }
+                if (wl * 64 > 16ll * 1024 * 1024) { too_large[(size_t)d] = 1; break; }
+                gap_to(ws);
+                set_bit(wbits, base + ws);
+                covered = pos = ws + wl;
+            }
+            gap_to(len);
+        }
+        regfree(&re);
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    return failed ? HUTK_E_VALUE : HUTK_OK;
+}
+
+static int encode_batch_regex(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                              int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status);
+
+int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (!pattern) {
+        c->pattern.clear();
+        return HUTK_OK;
+    }
+    if (c->tab.has_prefix)
+        return set_err(HUTK_E_UNSUPPORTED, "a regex pattern together with a prefix is not supported");
+    regex_t re;
+    if (!*pattern || regcomp(&re, pattern, REG_EXTENDED) != 0)
+        return set_err(HUTK_E_VALUE, "Regex could not be compiled.");  // core.c:352-358
+    regfree(&re);
+    c->pattern = pattern;
+    return HUTK_OK;
+}
+
 int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                       int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (c && !c->host_only && !c->pattern.empty())
+        return encode_batch_regex(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
     if (c && !c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
         offsets[n_docs] >= PIPE_MIN_BYTES && !getenv("HUTK_NO_PIPELINE")) {
         bool redo = false;
@@ -848,8 +955,38 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     }
 }
 
+static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                             int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
+                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits);
+
 static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                                int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    return encode_batch_host(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, nullptr, nullptr);
+}
+
+static int encode_batch_regex(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                              int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (n_docs < 0 || !offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
+    if (offsets[0] != 0) return set_err(HUTK_E_ARG, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n_docs; i++)
+        if (offsets[i + 1] < offsets[i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
+    if (offsets[n_docs] > 0 && !bytes) return set_err(HUTK_E_ARG, "bad argument");
+    for (int64_t i = 0; i < offsets[n_docs]; i++)  // (regexec would stop there; the packed interface refuses it anyway)
+        if (!bytes[i]) return set_err(HUTK_E_NUL_BYTE, "a document contains a 0x00 byte");
+    std::vector<uint32_t> wbits, gbits;
+    std::vector<uint8_t> too_large;
+    int rc = regex_bitmaps(c->pattern, bytes, offsets, n_docs, wbits, gbits, too_large);
+    if (rc) return set_err(rc, "Regex could not be compiled.");
+    rc = encode_batch_host(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, &wbits, &gbits);
+    if (rc == HUTK_OK && status)
+        for (int64_t d = 0; d < n_docs; d++)
+            if (too_large[(size_t)d]) status[d] = HUTK_DOC_WORD_TOO_LARGE;
+    return rc;
+}
+
+static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                             int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
+                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
     if (n_docs < 0 || !offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
@@ -870,8 +1007,17 @@ static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t*
     hipStream_t s = c->stream;
     if (n_bytes) HIP_TRY(hipMemcpyAsync(c->s_bytes.p, bytes, (size_t)n_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->s_offsets.p, offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
-    int rc = hutk_encode_batch_device(c, c->s_bytes.p, c->s_offsets.p, n_docs, n_bytes, c->s_ids.p, need,
-                                      c->s_out_offsets.p, c->s_status.p, c->w_err.p, s);
+    const uint32_t *d_wb = nullptr, *d_gb = nullptr;
+    if (wbits) {
+        HIP_TRY(c->w_wbits.reserve(wbits->size()));
+        HIP_TRY(c->w_gbits.reserve(gbits->size()));
+        HIP_TRY(hipMemcpyAsync(c->w_wbits.p, wbits->data(), wbits->size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->w_gbits.p, gbits->data(), gbits->size() * 4, hipMemcpyHostToDevice, s));
+        d_wb = c->w_wbits.p;
+        d_gb = c->w_gbits.p;
+    }
+    int rc = encode_device_impl(c, c->s_bytes.p, c->s_offsets.p, n_docs, n_bytes, c->s_ids.p, need,
+                                c->s_out_offsets.p, c->s_status.p, c->w_err.p, s, d_wb, d_gb);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_offsets, c->s_out_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
     int32_t err = 0;

@@ -117,6 +117,11 @@ struct BatchArgs {
     int64_t* out_offsets;
     int32_t* status;  // may be null
     int32_t* err;     // never null (workspace word when the caller passes none)
+    // regex pre-token path (a pattern was given to initialize): bit p of word_bits = a word or a dropped stretch starts
+    // at byte p (bits up to and including n_bytes, padded with zero words); bit p of gap_bits = what starts at p is a
+    // stretch no match covers (no ids).  Both null: the hand-written splitter (the automaton in k_tiles).
+    const uint32_t* word_bits;
+    const uint32_t* gap_bits;
 };
 
 // ---- decode direction (hutk_decode.hip) ----

@@ -505,12 +505,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
             bool exotic;
+            if (A.word_bits) {
+                // regex pre-token path (core.c:350-360, 372-378): the host ran the pattern over the documents; bit p of
+                // word_bits = a word (or a stretch no match covers, see gap_bits) starts at byte p
+                flags = reinterpret_cast<const uint16_t*>(A.word_bits)[(t0 >> 4) + lane];
+                exotic = false;
+            } else {
 #if HUTK_SPLIT_SWAR
-            flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
+                flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
 #else
-            flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.c.dfa), s_m.c.lut,
-                                   &exotic);                   // the automaton: one LDS lookup per byte
+                flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.c.dfa), s_m.c.lut,
+                                       &exotic);                   // the automaton: one LDS lookup per byte
 #endif
+            }
             if (exotic) {  // overlong encodings: per-position decode
                 Win8 w8;
     #pragma unroll
@@ -575,8 +582,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 // first word of a document with a prefix configured (core.c:364-366, 421-451): a leading space
                 // means "prefix ids as a word of their own, then the word as it is" (handled in the epilogue);
                 // otherwise the prefix units go in front of the word's own units (arena)
-                const bool pfx = T.has_prefix && docfirst && b0 != ' ';
-                bool exc = !known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst);
+                // regex pre-token path: text that no match covers is dropped (core.c:372-378 takes the LEFTMOST match at or
+                // after the cursor): such a stretch is a "word" without ids
+                const bool gap = A.gap_bits && ((A.gap_bits[(t0 + ws) >> 5] >> ((t0 + ws) & 31)) & 1u);
+                const bool pfx = !gap && T.has_prefix && docfirst && b0 != ' ';
+                bool exc = !gap && (!known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst));
                 if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
                     exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
                 // Every global load of this round is issued here, unconditionally and together, so that the round
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
                 //   encodes to; two-choice cuckoo tables, entries verified by this pipeline at context creation;
                 //   one table for words of 2..16 bytes, 20-byte slots {16 key bytes, symbol}
-                const bool probe = !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
+                const bool probe = !gap && !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
                 uint32_t k0, k1, k2, k3;
                 {
                     const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     }
                 }
                 const int n_cap = pfx ? ARENA_W : LANE_MAX_UNITS;
-                if (!exc && !done) {
+                if (!gap && !exc && !done) {
                     if (BYTE_MODE) {
                         n = nb;
                     } else {
@@ -664,7 +674,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     }
                     if (n > LANE_MAX_UNITS) exc = true;
                 }
-                if (done) {
+                if (gap) {
+                    atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));  // no ids
+                    done = true;
+                } else if (done) {
                 } else if (!BYTE_MODE && !exc && pfx) {  // arena word: at least two units, always through the merge loop
                     arena_ws[slot] = (uint16_t)ws;
                     arena_n[slot] = (uint16_t)n;
@@ -2035,7 +2048,24 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
         // word end, when the tile could not see it
         int64_t we = ws + rec.len;
         bool too_large = false;
-        if (rec.len < 0) {
+        if (rec.len < 0 && A.word_bits) {
+            // regex pre-token path: the word ends at the next start bit (the end of the data has one)
+            we = -1;
+            for (int64_t wi = (ws + 1) >> 5; we < 0; wi += 64) {
+                const int64_t w = wi + lane;
+                uint32_t bits = (w << 5) <= A.n_bytes ? A.word_bits[w] : 0u;
+                if (w == ((ws + 1) >> 5)) bits &= ~0u << ((ws + 1) & 31);
+                const unsigned long long bal = __ballot(bits != 0);
+                if (bal) {
+                    const int l0 = __builtin_ctzll(bal);
+                    const uint32_t b0 = (uint32_t)__shfl((int)bits, l0, 64);
+                    we = ((wi + l0) << 5) + __builtin_ctz(b0);
+                } else if ((wi << 5) > A.n_bytes) {
+                    we = A.n_bytes;  // (cannot happen: the host sets the bit at n_bytes)
+                }
+            }
+            if (we - ws > MAX_WORD_BYTES) too_large = true;
+        } else if (rec.len < 0) {
             we = -1;
             for (int64_t base = ws + 1; we < 0; base += EXC_CHUNK) {
                 if (base - ws > MAX_WORD_BYTES + 1) { too_large = true; break; }

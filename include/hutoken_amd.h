@@ -78,6 +78,16 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
                            const char* prefix, int is_byte_encoder, const char* merges_path,
                            int device);
 
+/* _hutoken.initialize's `pattern` (src/lib.c:188-205, 229-232): the regex pre-token path of encode(), src/core.c:350-360,
+ * 372-378, 392-400, 498-500.  `pattern` is a POSIX extended regular expression; the words of a document are the
+ * successive LEFTMOST matches at or after a cursor, text between them is dropped, an empty match moves the cursor one
+ * byte on.  Matching is libc's regcomp/regexec in the process's locale, exactly the calls the reference makes, run on
+ * the host by hutk_encode_batch / hutk_encode (one compiled pattern per host thread); pretokenizer and merge loop stay
+ * on the GPU.  NULL returns to the hand-written splitter (src/parser.c).  HUTK_E_VALUE: the pattern does not compile
+ * (the reference compares regcomp()'s result with `true` and goes on with an uncompiled pattern for every other error
+ * code); HUTK_E_UNSUPPORTED: the context has a prefix.  hutk_encode_batch_device refuses a context with a pattern. */
+int hutk_ctx_set_pattern(hutk_ctx* ctx, const char* pattern);
+
 /* The reference never frees its contexts (lib.c:129-155); this one can be. */
 void hutk_ctx_destroy(hutk_ctx* ctx);
 

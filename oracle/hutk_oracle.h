@@ -25,7 +25,8 @@ enum {
     HTO_DOC_OK = 0,
     HTO_DOC_WORD_TOO_LARGE = 1, /* core.c:402-407 */
     HTO_DOC_INVALID_UTF8 = 2,   /* reference behaviour undefined */
-    HTO_DOC_NOMEM = 3
+    HTO_DOC_NOMEM = 3,
+    HTO_DOC_BAD_PATTERN = 4
 };
 
 hto_ctx* hto_create(const char* vocab_path, const char* special_path,
@@ -38,6 +39,9 @@ void hto_destroy(hto_ctx* c);
 int hto_load_merges(hto_ctx* c, const char* path, char* err, size_t errcap);
 int hto_has_merges(const hto_ctx* c);
 uint64_t hto_rule_count(const hto_ctx* c);
+
+/* regex pre-token path (core.c:350-360): a POSIX ERE, or NULL for the hand-written splitter */
+int hto_set_pattern(hto_ctx* c, const char* pattern);
 
 uint64_t hto_vocab_count(const hto_ctx* c);
 int hto_vocab_lookup(const hto_ctx* c, const uint8_t* key, size_t len,

@@ -42,6 +42,8 @@ def lib():
         L.hto_destroy.argtypes = [C.c_void_p]
         L.hto_load_merges.restype = C.c_int
         L.hto_load_merges.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.hto_set_pattern.restype = C.c_int
+        L.hto_set_pattern.argtypes = [C.c_void_p, C.c_char_p]
         L.hto_has_merges.restype = C.c_int
         L.hto_has_merges.argtypes = [C.c_void_p]
         L.hto_rule_count.restype = C.c_uint64
@@ -96,7 +98,7 @@ def pack(texts):
 
 
 class Oracle:
-    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, merges_path=None):
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, merges_path=None, pattern=None):
         L = lib()
         kind = C.c_int(0)
         err = C.create_string_buffer(256)
@@ -109,6 +111,10 @@ class Oracle:
             rc = L.hto_load_merges(self._h, os.fsencode(merges_path), err, 256)
             if rc:
                 raise _ERR_KIND.get(rc, RuntimeError)(err.value.decode())
+        if pattern is not None:  # the regex pre-token path (core.c:350-360)
+            rc = L.hto_set_pattern(self._h, pattern.encode("utf-8"))
+            if rc:
+                raise _ERR_KIND.get(rc, RuntimeError)("Regex could not be compiled.")
 
     @property
     def has_merges(self):

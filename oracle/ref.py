@@ -56,10 +56,10 @@ class RefTokenizer:
     keeps ONE process-global context (lib.c:73-74): constructing a second
     RefTokenizer re-initialises it for every holder."""
 
-    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, merges_path=None):
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, merges_path=None, pattern=None):
         self.m = module()
-        # merges_path: the id-keyed merge path (lib.c:573-663, core.c:457-477)
-        self.m.initialize(vocab_path, special_path, prefix, is_byte_encoder, -1, None, merges_path)
+        # merges_path: the id-keyed merge path (lib.c:573-663, core.c:457-477); pattern: the regex pre-token path
+        self.m.initialize(vocab_path, special_path, prefix, is_byte_encoder, -1, pattern, merges_path)
 
     def encode(self, text):
         return self.m.encode(text)

@@ -62,7 +62,24 @@ def test_merges_file_arguments(hutoken, tmp_path):
 def test_out_of_path_features_fail_loudly(hutoken, tmp_path):
     ents, sp = H.random_byte_vocab(1, n_merges=20)
     vp, spath = H.write_vocab(tmp_path, "v", ents, sp)
-    with pytest.raises(RuntimeError, match="pattern"):
+    with pytest.raises(RuntimeError):  # (no GPU here: the context cannot be created)
         hutoken.initialize(vp, spath, pattern="[a-z]+")
     with pytest.raises(RuntimeError):
         hutoken.decode([1, 2, 3])
+
+
+def test_pattern_argument(tmp_path):
+    """initialize(pattern=...): a POSIX ERE (core.c:350-360).  One that does not compile is refused (the reference
+    goes on with an uncompiled pattern for most error codes); so is a pattern together with a prefix."""
+    from hutoken_amd import _capi
+    ents, sp = H.random_byte_vocab(1, n_merges=20)
+    vp, spath = H.write_vocab(tmp_path, "v", ents, sp)
+    ctx = _capi.Context(vp, spath, None, True, device=-2)
+    ctx.set_pattern("[ ]?[a-z]+|[ ]+")
+    ctx.set_pattern(None)
+    for bad in ("(", "[a-", "a{2,1}", ""):
+        with pytest.raises(ValueError, match="Regex could not be compiled."):
+            ctx.set_pattern(bad)
+    ctx = _capi.Context(vp, spath, "x", True, device=-2)
+    with pytest.raises(ValueError, match="prefix"):
+        ctx.set_pattern("[a-z]+")

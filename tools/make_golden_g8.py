@@ -10,6 +10,7 @@ reference (oracle/_ref, built from /root/reference by oracle/Makefile).  Run in 
   queue    push / pop sequences of the reference's MinPQ (src/queue.c:152-199; tests/test_queue.c:81-121, 146-178:
            equal ranks come out in left_idx order)
   ties     texts with repeated pairs x G1's byte vocabulary -> ids (the leftmost of equal ranks merges first)
+  --g9     g9_regex_path.json: the regex pre-token path (initialize(pattern=...)): POSIX EREs x seeded texts -> ids
 
 Files that make the reference write out of bounds (special index 256, ids >= the line count) are NOT run through it;
 they are deliberate deviations.
@@ -181,8 +182,53 @@ def g8(tmp):
     return out
 
 
+# G9: the regex pre-token path (initialize(pattern=...), core.c:350-360).  POSIX EREs x seeded texts -> ids.
+GPT2_POSIX = ("[ ]?[A-Za-z\u00e1\u00e9\u00ed\u00f3\u00fa\u0151\u0171\u00fc\u00f6\u00c1\u00c9\u00cd\u00d3\u00da\u0150\u00dc\u0170\u00d6]+|[ ]?[0-9]+|"
+              "[ ]?[^[:space:][:alpha:][:digit:]]+|[ ]+")  # tests/test_parser.c:10-12
+G9_PATTERNS = [GPT2_POSIX, "[a-z]+", " ?[[:alpha:]]+| ?[[:digit:]]+| ?[^[:space:][:alpha:][:digit:]]+|[[:space:]]+",
+               ".+", "x*", "[^ ]+", "(th|he)+", "^[a-z]+", "[[:alpha:]]+[[:space:]]?", "a|"]
+
+
+def g9_texts(seed, n):
+    rng = random.Random(seed)
+    return [H.random_text(rng, max_words=25) for _ in range(n)]
+
+
+def g9(tmp):
+    """needs LC_CTYPE = a UTF-8 locale (CPython's default C.UTF-8): recorded with the fixture"""
+    import locale
+    from hutoken_amd import data, synth
+    out = {"lc_ctype": locale.setlocale(locale.LC_CTYPE, None), "mid": [], "vg": None}
+    ents, sp = H.random_byte_vocab(11, n_merges=2000)
+    vp, spath = H.write_vocab(tmp, "g9", ents, sp)
+    texts = g9_texts(9000, 600)
+    for pat in G9_PATTERNS:
+        r = ref.RefTokenizer(vp, spath, None, True, pattern=pat)
+        res = r.batch_encode(texts, 4)
+        h = hashlib.sha256()
+        for ids in res:
+            h.update(json.dumps(ids).encode())
+        out["mid"].append({"pattern": pat, "first": res[:25], "n_ids": sum(len(x) for x in res), "sha256": h.hexdigest()})
+    vp, sp, kw = data.vocab_files("VG")
+    r = ref.RefTokenizer(vp, sp, kw["prefix"], kw["is_byte_encoder"], pattern=GPT2_POSIX)
+    d, o = synth.corpus("C3", 2000)
+    res = r.batch_encode(synth.docs_as_str(d, o), 8)
+    h = hashlib.sha256()
+    for ids in res:
+        h.update(json.dumps(ids).encode())
+    out["vg"] = {"pattern": GPT2_POSIX, "corpus": "C3", "n_docs": 2000, "first": res[:10],
+                 "n_ids": sum(len(x) for x in res), "sha256": h.hexdigest()}
+    return out
+
+
 def main():
     assert ref.available(), "build the reference first: make -C oracle ref"
+    if "--g9" in sys.argv:
+        res = g9(tempfile.mkdtemp())
+        with open(os.path.join(OUT, "g9_regex_path.json"), "w") as f:
+            json.dump(res, f, ensure_ascii=True, indent=0)
+        print(res["lc_ctype"], [(m["pattern"][:20], m["n_ids"]) for m in res["mid"]], res["vg"]["n_ids"])
+        return
     res = g8(tempfile.mkdtemp())
     with open(os.path.join(OUT, "g8_reference_fixtures.json"), "w") as f:
         json.dump(res, f, ensure_ascii=True, indent=0)
