@@ -53,6 +53,15 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
             or not (merges_file_path is None or isinstance(merges_file_path, str)) \
             or not isinstance(special_token_id, int):
         raise TypeError(_BAD_INIT_ARGS)
+    sh = _capi.shim()
+    if sh is not None:
+        # the compiled module with the reference's method table owns the context; this wrapper only looks at it
+        sh.initialize(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), special_token_id, pattern,
+                      merges_file_path, device)
+        old, _ctx = _ctx, _capi.Context.from_handle(sh.handle())
+        if old is not None:
+            old.close()
+        return None
     # merges_file_path: the id-keyed merge path (lib.c:573-663, core.c:211-337) on the same kernels
     new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device,
                         merges_path=merges_file_path)
@@ -130,6 +139,9 @@ def _pack(texts):
 
 
 def _native_encode(text):
+    sh = _capi.shim()
+    if sh is not None:
+        return sh.encode(text)
     if _ctx is None:
         raise RuntimeError(_NOT_INIT)
     if not isinstance(text, str):
@@ -142,6 +154,9 @@ def _native_encode(text):
 
 
 def _native_batch_encode(texts, num_threads=1):
+    sh = _capi.shim()
+    if sh is not None:
+        return sh.batch_encode(texts, num_threads)
     if _ctx is None:
         raise RuntimeError(_NOT_INIT)
     if not isinstance(texts, list):
@@ -222,6 +237,9 @@ def _ids_to_text(raw):
 
 def _native_decode(tokens):
     """_hutoken.decode (lib.c:876-951): list[int] -> str."""
+    sh = _capi.shim()
+    if sh is not None:
+        return sh.decode(tokens)
     import numpy as np
     if _ctx is None:
         raise RuntimeError(_NOT_INIT_DECODE)
@@ -234,6 +252,9 @@ def _native_decode(tokens):
 
 def _native_batch_decode(tokens, num_threads=1):
     """_hutoken.batch_decode (lib.c:954-1126): list[list[int]] -> list[str]."""
+    sh = _capi.shim()
+    if sh is not None:
+        return sh.batch_decode(tokens, num_threads)
     import numpy as np
     if _ctx is None:
         raise RuntimeError(_NOT_INIT_DECODE)

@@ -120,6 +120,30 @@ def load(build_if_missing=True):
     return L
 
 
+_shim = False
+
+
+def shim():
+    """The compiled CPython shim (csrc/pyshim/_hutoken_amd.c: the reference's _hutoken method table on this library), or
+    None when it is not built or HUTOKEN_AMD_NO_SHIM is set.  Loaded after the library itself (see load())."""
+    global _shim
+    if _shim is False:
+        _shim = None
+        path = _build.LIB_PYSHIM
+        if not os.environ.get("HUTOKEN_AMD_NO_SHIM") and not os.environ.get("HUTOKEN_AMD_LIB"):
+            try:
+                if not os.path.exists(path):
+                    _build.build_pyshim()
+                load()
+                spec = importlib.util.spec_from_file_location("_hutoken_amd", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _shim = mod
+            except Exception:  # no compiler, no Python.h: the ctypes path does the same work
+                _shim = None
+    return _shim
+
+
 def last_error():
     return load().hutk_last_error().decode("utf-8", "replace")
 
@@ -173,6 +197,15 @@ class Context:
                                       None if merges_path is None else os.fsencode(merges_path), device)
         raise_for(rc)
         self._h = h
+        self._owned = True
+
+    @classmethod
+    def from_handle(cls, address):
+        """A view of a hutk_ctx that somebody else owns (the CPython shim's module-global context)."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(address)
+        self._owned = False
+        return self
 
     def set_pattern(self, pattern):
         """The regex pre-token path (initialize's `pattern`, a POSIX ERE); None: the hand-written splitter."""
@@ -185,7 +218,8 @@ class Context:
 
     def close(self):
         if getattr(self, "_h", None):
-            load().hutk_ctx_destroy(self._h)
+            if getattr(self, "_owned", True):
+                load().hutk_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
