@@ -23,6 +23,8 @@
 using namespace hutk;
 
 namespace {
+constexpr int64_t SMALL_BYTES = 32 * 1024, SMALL_DOCS = 1024;
+constexpr size_t SMALL_HOST_BYTES = 256 * 1024;
 thread_local std::string g_err = "";
 
 int set_err(int code, const std::string& msg) {
@@ -106,6 +108,9 @@ struct hutk_ctx {
     DevBuf<uint8_t> s_bytes;
     DevBuf<int64_t> s_offsets, s_out_offsets;
     DevBuf<int32_t> s_ids, s_status;
+    // small batches: one page-locked host buffer, one device buffer each way
+    DevBuf<uint8_t> s_small_in, s_small_out;
+    void* small_host = nullptr;
     // pipelined host path (hutk_encode_batch on large batches): two sets of chunk buffers, copy streams,
     // pinned staging for the rebased offsets and the small per-chunk results
     struct Pipe {
@@ -303,7 +308,8 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_ndefer = u + 6 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
-    W.scan_part = c->w_tile_i64.p + 2 * n_tiles + 2;
+    W.scan_state = reinterpret_cast<unsigned long long*>(c->w_tile_i64.p + 2 * n_tiles + 2);
+    W.n_scan_blocks = scan_blocks(n_tiles);
     W.doc_tile_pos = c->w_doc_pos.p;
     W.exc = c->w_exc.p;
     W.exc_long = c->w_exc_long.p;
@@ -336,7 +342,8 @@ void destroy(hutk_ctx* c) {
         c->dw_state.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
         c->ds_offs.release(); c->ds_oo.release(); c->ds_bytes.release(); c->w_err.release();
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
-        c->s_status.release();
+        c->s_status.release(); c->s_small_in.release(); c->s_small_out.release();
+        if (c->small_host) (void)hipHostFree(c->small_host);
         for (int b = 0; b < 2; b++) {
             c->pipe.bytes[b].release(); c->pipe.offs[b].release(); c->pipe.oo[b].release(); c->pipe.offs_abs[b].release();
             c->pipe.ids[b].release(); c->pipe.status[b].release(); c->pipe.err[b].release();
@@ -579,10 +586,9 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
 
     c->ev_valid = false;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
-    HIP_TRY(hipMemsetAsync(A.err, 0, 4, s));
-    HIP_TRY(hipMemsetAsync(W.counters, 0, 32, s));
-    if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
     if (n_tiles == 0) {
+        HIP_TRY(hipMemsetAsync(A.err, 0, 4, s));
+        if (d_status && n_docs) HIP_TRY(hipMemsetAsync(d_status, 0, (size_t)n_docs * 4, s));
         HIP_TRY(hipMemsetAsync(d_out_offsets, 0, (size_t)(n_docs + 1) * 8, s));
         if (c->timing) {
             HIP_TRY(hipEventRecord(c->ev[1], s));
@@ -599,8 +605,7 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     launch_merge(c->dt, A, W, s);  // (before the exception kernels: it sets a tile's id count, they add to it)
     launch_exceptions(c->dt, A, W, s);
     launch_scan(A, W, s);
-    launch_gather(c->dt, A, W, s);
-    launch_doc_offsets(A, W, s);
+    launch_finish(c->dt, A, W, s);
     HIP_TRY(hipGetLastError());
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], s));
@@ -998,13 +1003,53 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
     const int64_t need = hutk_ids_capacity(c, n_bytes, n_docs) - 1;
     if (ids_cap < need) return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
     HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // Small batches (one sentence, a few documents) are bound by the number of copies and launches, not by their size:
+    // offsets and bytes go up as ONE copy from a page-locked staging buffer, and out_offsets, error word, status and
+    // ids come back as ONE copy, instead of two up and four down.
+    if (!wbits && n_bytes > 0 && n_bytes <= SMALL_BYTES && n_docs <= SMALL_DOCS) {
+        const size_t in_offs = 0, in_bytes = (((size_t)n_docs + 1) * 8 + 15) & ~(size_t)15;
+        const size_t in_size = in_bytes + (size_t)n_bytes;
+        const size_t o_oo = 0, o_err = ((size_t)n_docs + 1) * 8, o_st = o_err + 8, o_ids = (o_st + (size_t)n_docs * 4 + 15) & ~(size_t)15;
+        const size_t out_size = o_ids + (size_t)need * 4;
+        if (!c->small_host) {
+            if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocDefault) != hipSuccess) c->small_host = nullptr;
+        }
+        if (c->small_host && in_size <= SMALL_HOST_BYTES && out_size <= SMALL_HOST_BYTES) {
+            HIP_TRY(c->s_small_in.reserve(in_size + 64));
+            HIP_TRY(c->s_small_out.reserve(out_size + 64));
+            uint8_t* h = static_cast<uint8_t*>(c->small_host);
+            memcpy(h + in_offs, offsets, ((size_t)n_docs + 1) * 8);
+            memcpy(h + in_bytes, bytes, (size_t)n_bytes);
+            HIP_TRY(hipMemcpyAsync(c->s_small_in.p, h, in_size, hipMemcpyHostToDevice, s));
+            uint8_t* di = c->s_small_in.p;
+            uint8_t* dout = c->s_small_out.p;
+            int rc = encode_device_impl(c, di + in_bytes, reinterpret_cast<const int64_t*>(di + in_offs), n_docs, n_bytes,
+                                        reinterpret_cast<int32_t*>(dout + o_ids), need, reinterpret_cast<int64_t*>(dout + o_oo),
+                                        reinterpret_cast<int32_t*>(dout + o_st), reinterpret_cast<int32_t*>(dout + o_err), s,
+                                        nullptr, nullptr);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpyAsync(h, dout, out_size, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            int32_t err = 0;
+            memcpy(&err, h + o_err, 4);
+            if (err == HUTK_OK) {
+                memcpy(out_offsets, h + o_oo, ((size_t)n_docs + 1) * 8);
+                const int64_t total = out_offsets[n_docs];
+                if (total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
+                if (total) memcpy(ids_out, h + o_ids, (size_t)total * 4);
+                if (status && n_docs) memcpy(status, h + o_st, (size_t)n_docs * 4);
+                return HUTK_OK;
+            }
+            // (an error or a cut document: the general path below reports it)
+        }
+    }
     HIP_TRY(c->s_bytes.reserve((size_t)n_bytes + 64));
     HIP_TRY(c->s_offsets.reserve((size_t)n_docs + 1));
     HIP_TRY(c->s_out_offsets.reserve((size_t)n_docs + 1));
     HIP_TRY(c->s_ids.reserve((size_t)need + 1));
     HIP_TRY(c->s_status.reserve((size_t)n_docs + 1));
     HIP_TRY(c->w_err.reserve(1));
-    hipStream_t s = c->stream;
     if (n_bytes) HIP_TRY(hipMemcpyAsync(c->s_bytes.p, bytes, (size_t)n_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->s_offsets.p, offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     const uint32_t *d_wb = nullptr, *d_gb = nullptr;

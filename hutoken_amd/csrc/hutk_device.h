@@ -93,7 +93,8 @@ struct Workspace {
     uint32_t* tile_nexc;       // [n_tiles]
     int64_t* tile_first_doc;   // [n_tiles] first document whose offset is >= tile start - LOOKBACK
     int64_t* tile_base;        // [n_tiles + 1] exclusive scan of tile_count
-    int64_t* scan_part;        // [n_tiles / 2048 + 1] block totals / bases of that scan
+    unsigned long long* scan_state;  // [n_scan_blocks] k_scan's decoupled look-back: flag (2 bits) | total or inclusive prefix
+    int64_t n_scan_blocks;
     uint32_t* doc_tile_pos;    // [n_docs + 1] ids the owning tile emits before the document start
     ExcRec* exc;               // [cap_exc]
     uint32_t* exc_long;        // [cap_exc] records k_exc_medium left (count: counters[3]); the ends pass splits them:
@@ -161,8 +162,9 @@ void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
 bool tiles_defer(const DevTables& t);  // k_tiles leaves the merge loop to k_merge for this context
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
-void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
-void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s);
+int64_t scan_blocks(int64_t n_tiles);
+// tile runs (+ exception words) -> ids_out, out_offsets: one launch
+void launch_finish(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // one-off at context creation: merge a symbol sequence on the device, return ids
 void launch_bpe_symbols(const DevTables& t, uint32_t* d_syms, int n, int32_t* d_ids_out,
                         int32_t* d_n_out, hipStream_t s);

@@ -238,6 +238,14 @@ __device__ __forceinline__ uint64_t bits64(const uint32_t* m, int start) {
 // ------------------------------------------------------------------------
 __global__ void k_pre(BatchArgs A, Workspace W) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // what the kernels behind this one add to or publish in: error word, counters, per-document status, scan states
+    // (here rather than in memsets of their own: a batch is a handful of launches)
+    if (t == 0) *A.err = 0;
+    if (t < 8) W.counters[t] = 0;
+    const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
+    if (A.status)
+        for (int64_t d = t; d < A.n_docs; d += n_threads) A.status[d] = 0;
+    for (int64_t b = t; b < W.n_scan_blocks; b += n_threads) W.scan_state[b] = 0;
     if (t >= A.n_tiles) return;
     const int64_t gw = t * TILE_BYTES - LOOKBACK;
     int64_t lo = 0, hi = A.n_docs + 1;  // first d in [0, n_docs] with offsets[d] >= gw
@@ -1661,15 +1669,17 @@ __device__ __forceinline__ int64_t doc_of(const BatchArgs& A, const Workspace& W
 // ------------------------------------------------------------------------
 constexpr int MEDIUM_UNITS = 64;
 template <typename SymT>
-__global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Workspace W) {
+__device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                             uint32_t vgrid, uint8_t* lds) {
     // 16-bit symbols when the vocabulary allows: half the LDS, twice the resident wavefronts (the loop is
     // bound by the latency of its pair lookups)
-    __shared__ SymT Sm[MEDIUM_UNITS * 64];  // unit i of the lane's word at [i * 64 + lane]
-    __shared__ SymT Mm[MEDIUM_UNITS * 64];  // merged symbol of (unit i, next live unit) or NONE
+    // unit i of the lane's word at Sm[i * 64 + lane]; Mm: merged symbol of (unit i, next live unit) or NONE
+    SymT* const Sm = reinterpret_cast<SymT*>(lds);
+    SymT* const Mm = Sm + MEDIUM_UNITS * 64;
     const int lane = threadIdx.x;
     const uint32_t n_exc = W.counters[0];
-    for (uint64_t base = (uint64_t)blockIdx.x * 64; base < n_exc && (int64_t)base < W.cap_exc;
-         base += (uint64_t)gridDim.x * 64) {
+    for (uint64_t base = (uint64_t)vblock * 64; base < n_exc && (int64_t)base < W.cap_exc;
+         base += (uint64_t)vgrid * 64) {
         const uint64_t idx = base + lane;
         bool have = idx < n_exc && (int64_t)idx < W.cap_exc;
         ExcRec rec{};
@@ -1813,14 +1823,22 @@ __global__ __launch_bounds__(64) void k_exc_medium(DevTables T, BatchArgs A, Wor
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        // what is left goes on k_exc's list: one atomic per wavefront, not one per record
-        const bool leave = !have && idx < n_exc && (int64_t)idx < W.cap_exc;
-        const unsigned long long lb = __ballot(leave);
-        if (lb) {
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(&W.counters[3], (uint32_t)__popcll(lb));
-            at = __shfl(at, 0, 64);
-            if (leave) W.exc_long[at + __popcll(lb & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        // A word of known length that is not taken here (prefix units make it longer than MEDIUM_UNITS) goes straight on
+        // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
+        const bool leave = !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0;
+        const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym;  // (prefix units + 63 bytes <= QUAD_UNITS)
+        const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
+        if (bq | bw) {
+            uint32_t aq = 0, aw = 0;
+            if (lane == 0) {
+                if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
+                if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
+            }
+            aq = __shfl(aq, 0, 64);
+            aw = __shfl(aw, 0, 64);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (to_quad) W.exc_quad[aq + __popcll(bq & below)] = (uint32_t)idx;
+            else if (leave) W.exc_wave[aw + __popcll(bw & below)] = (uint32_t)idx;
         }
     }
 }
@@ -1849,14 +1867,15 @@ __device__ __forceinline__ uint32_t row_excl_sum(uint32_t v) {  // exclusive pre
     return inc - v;
 }
 
-__global__ __launch_bounds__(64) void k_exc_quad(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ uint32_t Sq[4 * QUAD_UNITS];
-    __shared__ uint32_t Mq[4 * QUAD_UNITS];
+__device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                           uint32_t vgrid, uint8_t* lds) {
+    uint32_t* const Sq = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* const Mq = Sq + 4 * QUAD_UNITS;
     const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, gl0 = lane & 48;  // group, lane in group, its lane 0
     uint32_t* Sg = Sq + g * QUAD_UNITS;
     uint32_t* Mg = Mq + g * QUAD_UNITS;
     const uint32_t n_list = W.counters[4];
-    for (uint32_t base = blockIdx.x * 4; base < n_list; base += gridDim.x * 4) {
+    for (uint32_t base = vblock * 4; base < n_list; base += vgrid * 4) {
         const uint32_t li = base + g;
         bool have = li < n_list;
         uint32_t idx = 0;
@@ -1986,136 +2005,151 @@ __global__ __launch_bounds__(64) void k_exc_quad(DevTables T, BatchArgs A, Works
     }
 }
 
-// After the ends pass: the list k_exc_medium left is split into k_exc_quad's and k_exc's lists, 64 entries per
-// wavefront and one atomic per wavefront and list (one per record would serialise on the counter).
-__global__ __launch_bounds__(64) void k_exc_split(Workspace W) {
-    const int lane = threadIdx.x;
-    const uint32_t n_list = W.counters[3];
-    for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
-        const uint32_t li = base + lane;
-        uint32_t idx = 0;
-        int64_t cls = 0;
-        if (li < n_list) {
-            idx = W.exc_long[li];
-            const ExcRec r = W.exc[idx];
-            cls = (r.tok_base < 0) ? 0 : r.out_pos;  // cut documents (over-long word) are on no list
+// End of a word whose end its tile could not see (more than 63 bytes, or beyond the tile's window): the splitter's rule
+// applied 256 positions at a time (src/parser.c:24-183 as in k_tiles' exact form), or -- regex pre-token path -- the next
+// start bit of the host's bitmap.  One wavefront; sb / scode / docm are its LDS scratch.  -> end offset; *too_large when
+// the word passes the reference's limit (core.c:402-407).
+__device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t ds, int64_t de, uint8_t* sb, uint8_t* scode,
+                                uint32_t* docm, int lane, bool* too_large) {
+    int64_t we = -1;
+    *too_large = false;
+    if (A.word_bits) {
+        for (int64_t wi = (ws + 1) >> 5; we < 0; wi += 64) {
+            const int64_t w = wi + lane;
+            uint32_t bits = (w << 5) <= A.n_bytes ? A.word_bits[w] : 0u;
+            if (w == ((ws + 1) >> 5)) bits &= ~0u << ((ws + 1) & 31);
+            const unsigned long long bal = __ballot(bits != 0);
+            if (bal) {
+                const int l0 = __builtin_ctzll(bal);
+                const uint32_t b0 = (uint32_t)__shfl((int)bits, l0, 64);
+                we = ((wi + l0) << 5) + __builtin_ctz(b0);
+            } else if ((wi << 5) > A.n_bytes) {
+                we = A.n_bytes;  // (cannot happen: the host sets the bit at n_bytes)
+            }
         }
-        const unsigned long long bq = __ballot(cls == 1), bw = __ballot(cls == 2);
+        if (we - ws > MAX_WORD_BYTES) *too_large = true;
+        return we;
+    }
+    for (int64_t base = ws + 1; we < 0; base += EXC_CHUNK) {
+        if (base - ws > MAX_WORD_BYTES + 1) { *too_large = true; break; }
+        const int64_t g0 = base - 16;  // global offset of window index 0
+        for (int i = lane; i < EXC_WIN; i += 64) {
+            const int64_t q = g0 + i;
+            sb[i] = (q >= ds && q < de) ? A.bytes[q] : (uint8_t)0;
+        }
+        if (lane < EXC_WIN / 32 + 1) docm[lane] = 0;
+        wave_sync();
+        if (lane == 0) {
+            if (ds >= g0 && ds < g0 + EXC_WIN) docm[(ds - g0) >> 5] |= 1u << ((ds - g0) & 31);
+            if (de >= g0 && de < g0 + EXC_WIN) docm[(de - g0) >> 5] |= 1u << ((de - g0) & 31);
+        }
+        wave_sync();
+        for (int i = lane; i < EXC_WIN; i += 64)
+            scode[i] = (i >= 4 && i < EXC_WIN - 4) ? code_at(sb, docm, i) : (uint8_t)C_BAD;
+        wave_sync();
+        for (int r0 = 0; r0 < EXC_CHUNK && we < 0; r0 += 64) {
+            const int64_t q = base + r0 + lane;
+            const bool f = (q <= de) && word_starts(scode, docm, 16 + r0 + lane);
+            const unsigned long long bal = __ballot(f);
+            if (bal) we = base + r0 + __builtin_ctzll(bal);
+        }
+        wave_sync();
+    }
+    return we;
+}
+
+// d_exc_ends: the words whose end their tile could not see.  One wavefront per tile that has exception words (the list
+// k_tiles made): for each such word of the tile the end is found and stored, and the word goes on k_exc_quad's list (16
+// lanes per word, up to QUAD_UNITS units, byte mode with rank == symbol order) or on k_exc's (a wavefront per word) --
+// collected per tile, one atomic per tile and list.  A word over the reference's limit cuts its document (no list).
+constexpr int ENDS_LIST = TILE_BYTES / 2 + 4;  // a tile has at most that many exception words
+struct EndsLds {
+    __attribute__((aligned(16))) uint8_t sb[EXC_WIN];
+    uint8_t scode[EXC_WIN];
+    uint32_t docm[EXC_WIN / 32 + 1];
+    uint32_t lq[ENDS_LIST], lw[ENDS_LIST];
+};
+constexpr uint32_t ENDS_SHARE = 4;  // wavefronts that share the words of one tile (word e goes to wavefront e % ENDS_SHARE)
+__device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                           uint32_t vgrid, uint8_t* lds) {
+    EndsLds& L = *reinterpret_cast<EndsLds*>(lds);
+    uint8_t* const sb = L.sb;
+    uint8_t* const scode = L.scode;
+    uint32_t* const docm = L.docm;
+    uint32_t* const lq = L.lq;
+    uint32_t* const lw = L.lw;
+    const int lane = threadIdx.x;
+    const uint32_t n_tiles_exc = W.counters[1];
+    const uint32_t sub = vblock % ENDS_SHARE;
+    for (uint32_t ti = vblock / ENDS_SHARE; ti < n_tiles_exc; ti += vgrid / ENDS_SHARE) {
+        const uint32_t tile = W.exc_tiles[ti];
+        const uint32_t first = W.tile_exc_first[tile], nexc = W.tile_nexc[tile];
+        uint32_t nq = 0, nw = 0;  // (the same in every lane)
+        for (uint32_t e = sub; e < nexc; e += ENDS_SHARE) {
+            const uint32_t idx = first + e;
+            if ((int64_t)idx >= W.cap_exc) break;
+            const ExcRec rec = W.exc[idx];
+            if (rec.len >= 0) continue;  // d_exc_medium's
+            const int64_t ws = rec.ws;
+            const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
+            bool too_large;
+            const int64_t we = exc_word_end(A, ws, ds, de, sb, scode, docm, lane, &too_large);
+            const int64_t nb = too_large ? 0 : we - ws;
+            if (too_large || nb > MAX_WORD_BYTES) {
+                if (lane == 0) {
+                    raise(A.err, HUTK_E_WORD_TOO_LARGE);
+                    if (A.status) A.status[d] = HUTK_DOC_WORD_TOO_LARGE;
+                    W.exc[idx].cnt = 0;
+                    W.exc[idx].tok_base = -(ws - ds) - 1;  // where the document is cut (negative marks "no ids")
+                }
+                continue;
+            }
+            const bool pfx_units = T.has_prefix && ws == ds && A.bytes[ws] != ' ';
+            const bool quad = T.is_byte_encoder && T.rank_is_sym && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
+            if (lane == 0) {
+                W.exc[idx].len = (int32_t)nb;
+                if (quad) lq[nq] = idx; else lw[nw] = idx;
+            }
+            if (quad) nq++; else nw++;
+        }
+        wave_sync();
         uint32_t aq = 0, aw = 0;
         if (lane == 0) {
-            if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
-            if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
+            if (nq) aq = atomicAdd(&W.counters[4], nq);
+            if (nw) aw = atomicAdd(&W.counters[5], nw);
         }
         aq = __shfl(aq, 0, 64);
         aw = __shfl(aw, 0, 64);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (cls == 1) W.exc_quad[aq + __popcll(bq & below)] = idx;
-        if (cls == 2) W.exc_wave[aw + __popcll(bw & below)] = idx;
+        for (uint32_t i = lane; i < nq; i += 64) W.exc_quad[aq + i] = lq[i];
+        for (uint32_t i = lane; i < nw; i += 64) W.exc_wave[aw + i] = lw[i];
+        wave_sync();
     }
 }
 
-// ENDS_ONLY: first pass over the list -- find the end of every word whose end the tile could not see and
-// store its length (k_exc_quad needs it); the regular pass then skips what k_exc_quad has encoded.
-template <bool ENDS_ONLY>
-__global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ uint32_t Sl[EXC_LDS_UNITS];
-    __shared__ uint32_t Ml[EXC_LDS_UNITS];
-    __shared__ __attribute__((aligned(16))) uint8_t sb[EXC_WIN];
-    __shared__ uint8_t scode[EXC_WIN];
-    __shared__ uint32_t docm[EXC_WIN / 32 + 1];
+// d_exc: the words that need a whole wavefront (k_exc's list; their lengths are known by now): first entry by block
+// index, further ones from a device cursor.
+__device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                      uint32_t vgrid, uint8_t* lds) {
+    uint32_t* const Sl = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* const Ml = Sl + EXC_LDS_UNITS;
     __shared__ uint32_t s_idx;
 
     const int lane = threadIdx.x;
-    const uint32_t n_list = ENDS_ONLY ? W.counters[3] : W.counters[5];
+    const uint32_t n_list = W.counters[5];
     for (uint32_t round = 0;; round++) {
-        // ENDS_ONLY: cheap and even work, static striding.  Regular pass: first entry by block index, further
-        // ones from a device cursor (its list holds only the words that need a whole wavefront)
-        uint32_t li = blockIdx.x;
-        if (ENDS_ONLY) {
-            li = blockIdx.x + round * gridDim.x;
-        } else if (round) {
-            if (lane == 0) s_idx = gridDim.x + atomicAdd(&W.counters[2], 1u);
+        uint32_t li = vblock;
+        if (round) {
+            if (lane == 0) s_idx = vgrid + atomicAdd(&W.counters[2], 1u);
             __syncthreads();
             li = s_idx;
             __syncthreads();
         }
         if (li >= n_list) break;
-        const uint32_t idx = ENDS_ONLY ? W.exc_long[li] : W.exc_wave[li];
+        const uint32_t idx = W.exc_wave[li];
         ExcRec rec = W.exc[idx];
         const int64_t ws = rec.ws;
-        const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
-
-        // word end, when the tile could not see it
-        int64_t we = ws + rec.len;
-        bool too_large = false;
-        if (rec.len < 0 && A.word_bits) {
-            // regex pre-token path: the word ends at the next start bit (the end of the data has one)
-            we = -1;
-            for (int64_t wi = (ws + 1) >> 5; we < 0; wi += 64) {
-                const int64_t w = wi + lane;
-                uint32_t bits = (w << 5) <= A.n_bytes ? A.word_bits[w] : 0u;
-                if (w == ((ws + 1) >> 5)) bits &= ~0u << ((ws + 1) & 31);
-                const unsigned long long bal = __ballot(bits != 0);
-                if (bal) {
-                    const int l0 = __builtin_ctzll(bal);
-                    const uint32_t b0 = (uint32_t)__shfl((int)bits, l0, 64);
-                    we = ((wi + l0) << 5) + __builtin_ctz(b0);
-                } else if ((wi << 5) > A.n_bytes) {
-                    we = A.n_bytes;  // (cannot happen: the host sets the bit at n_bytes)
-                }
-            }
-            if (we - ws > MAX_WORD_BYTES) too_large = true;
-        } else if (rec.len < 0) {
-            we = -1;
-            for (int64_t base = ws + 1; we < 0; base += EXC_CHUNK) {
-                if (base - ws > MAX_WORD_BYTES + 1) { too_large = true; break; }
-                const int64_t g0 = base - 16;  // global offset of window index 0
-                for (int i = lane; i < EXC_WIN; i += 64) {
-                    const int64_t q = g0 + i;
-                    sb[i] = (q >= ds && q < de) ? A.bytes[q] : (uint8_t)0;
-                }
-                if (lane < EXC_WIN / 32 + 1) docm[lane] = 0;
-                __syncthreads();
-                if (lane == 0) {
-                    if (ds >= g0 && ds < g0 + EXC_WIN) docm[(ds - g0) >> 5] |= 1u << ((ds - g0) & 31);
-                    if (de >= g0 && de < g0 + EXC_WIN) docm[(de - g0) >> 5] |= 1u << ((de - g0) & 31);
-                }
-                __syncthreads();
-                for (int i = lane; i < EXC_WIN; i += 64)
-                    scode[i] = (i >= 4 && i < EXC_WIN - 4) ? code_at(sb, docm, i) : (uint8_t)C_BAD;
-                __syncthreads();
-                for (int r0 = 0; r0 < EXC_CHUNK && we < 0; r0 += 64) {
-                    const int64_t q = base + r0 + lane;
-                    const bool f = (q <= de) && word_starts(scode, docm, 16 + r0 + lane);
-                    const unsigned long long bal = __ballot(f);
-                    if (bal) we = base + r0 + __builtin_ctzll(bal);
-                }
-                __syncthreads();
-            }
-        }
-        const int64_t nb = too_large ? 0 : we - ws;
-        if (too_large || nb > MAX_WORD_BYTES) {
-            if (lane == 0) {
-                raise(A.err, HUTK_E_WORD_TOO_LARGE);
-                if (A.status) A.status[d] = HUTK_DOC_WORD_TOO_LARGE;
-                rec.cnt = 0;
-                rec.tok_base = -(ws - ds) - 1;  // where the document is cut (negative marks "no ids")
-                W.exc[idx] = rec;
-            }
-            continue;
-        }
-
-        if (ENDS_ONLY) {
-            // length known now; hand the word to k_exc_quad (16 lanes per word, up to QUAD_UNITS units, byte mode
-            // with rank == symbol order) or to the regular pass (a wavefront per word)
-            if (lane == 0) {
-                W.exc[idx].len = (int32_t)nb;
-                const bool pfx_units = T.has_prefix && ws == ds && A.bytes[ws] != ' ';
-                const bool quad = T.is_byte_encoder && T.rank_is_sym && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
-                W.exc[idx].out_pos = quad ? 1 : 2;  // k_exc_split builds the two lists (out_pos is free until k_gather_exc)
-            }
-            continue;
-        }
+        const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d];
+        const int64_t nb = rec.len;
         const bool docfirst = (ws == ds);
         const bool with_prefix = T.has_prefix && docfirst;
         const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
@@ -2199,6 +2233,27 @@ __global__ __launch_bounds__(64) void k_exc(DevTables T, BatchArgs A, Workspace 
     }
 }
 
+// The exception words in TWO launches (their kernels do nothing at all in most batches, and a launch is ~5 us):
+//   k_exc_a  workgroups [0, n_medium): d_exc_medium, words of known length up to 63 bytes, one per lane;
+//            the others: d_exc_ends, the lengths of the words whose end no tile saw, and the two lists for ...
+//   k_exc_b  workgroups [0, EXB_QUAD): d_exc_quad, sixteen lanes per word; the others: d_exc, a wavefront per word
+// The two roles of a launch share one LDS area (a role's arrays would otherwise be allocated for every workgroup).
+constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUAD = 5120, EXB_WAVE = 4096;
+constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
+template <typename SymT>
+__global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspace W, uint32_t n_medium) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds))];
+    if (W.counters[0] == 0) return;  // no exception word in this batch
+    if (blockIdx.x < n_medium) d_exc_medium<SymT>(T, A, W, blockIdx.x, n_medium, lds);
+    else d_exc_ends(T, A, W, blockIdx.x - n_medium, gridDim.x - n_medium, lds);
+}
+__global__ __launch_bounds__(64) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4)];
+    if (W.counters[0] == 0) return;
+    if (blockIdx.x < (uint32_t)EXB_QUAD) d_exc_quad(T, A, W, blockIdx.x, EXB_QUAD, lds);
+    else d_exc(T, A, W, blockIdx.x - EXB_QUAD, EXB_WAVE, lds);
+}
+
 // one-off: merge a short symbol sequence (the prefix encoded as its own word)
 __global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, uint32_t* syms, int n, int32_t* ids_out,
                                                      int32_t* n_out) {
@@ -2217,12 +2272,14 @@ __global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, uint32_t* syms,
 }
 
 // ------------------------------------------------------------------------
-// exclusive scan of tile_count -> tile_base in three small launches:
-//   k_scan_sums   one workgroup per 2048 tiles: its total            -> scan_part[b]
-//   k_scan_parts  one workgroup: exclusive scan of the block totals  -> scan_part[b], grand total
-//   k_scan_apply  one workgroup per 2048 tiles: local exclusive scan + block base -> tile_base
+// k_scan: exclusive scan of tile_count -> tile_base (and the grand total at tile_base[n_tiles]) in ONE launch.  A workgroup
+// scans SCAN_BLOCK tiles, publishes its total at once and its inclusive prefix as soon as it knows it; it adds up its
+// predecessors' totals back to the nearest published prefix (decoupled look-back, as hutk_decode.hip does: workgroups
+// are dispatched in index order, so every predecessor is running or done).  Flag and value share one 64-bit word, so
+// relaxed agent-scope atomics suffice.  A bounded spin turns a broken premise into HUTK_E_DEVICE instead of a hang.
 // ------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 2048, SCAN_THREADS = 256, SCAN_PER_THREAD = SCAN_BLOCK / SCAN_THREADS;
+constexpr unsigned long long SC_MASK = 3ull << 62, SC_TOTAL = 1ull << 62, SC_PREFIX = 2ull << 62;
 
 __device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* sh, int tid, int n, int64_t* total) {
     sh[tid] = v;
@@ -2237,40 +2294,12 @@ __device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* sh, int t
     return sh[tid] - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(BatchArgs A, Workspace W) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan(BatchArgs A, Workspace W) {
     __shared__ int64_t sh[SCAN_THREADS];
+    __shared__ int64_t s_base;
     const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
-    int64_t sum = 0;
-    for (int k = 0; k < SCAN_PER_THREAD; k++)
-        if (base + k < A.n_tiles) sum += W.tile_count[base + k];
-    int64_t total;
-    (void)block_excl_scan(sum, sh, tid, SCAN_THREADS, &total);
-    if (tid == 0) W.scan_part[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void k_scan_parts(BatchArgs A, Workspace W, int64_t n_blocks) {
-    __shared__ int64_t sh[1024];
-    const int tid = threadIdx.x;
-    const int64_t chunk = (n_blocks + 1023) / 1024;
-    const int64_t a = tid * chunk < n_blocks ? tid * chunk : n_blocks;
-    const int64_t b = a + chunk < n_blocks ? a + chunk : n_blocks;
-    int64_t sum = 0;
-    for (int64_t i = a; i < b; i++) sum += W.scan_part[i];
-    int64_t total;
-    int64_t run = block_excl_scan(sum, sh, tid, 1024, &total);
-    for (int64_t i = a; i < b; i++) {
-        const int64_t v = W.scan_part[i];
-        W.scan_part[i] = run;
-        run += v;
-    }
-    if (tid == 0) W.tile_base[A.n_tiles] = total;
-}
-
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(BatchArgs A, Workspace W) {
-    __shared__ int64_t sh[SCAN_THREADS];
-    const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
+    const int64_t blk = blockIdx.x;
+    const int64_t base = blk * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
     uint32_t c[SCAN_PER_THREAD];
     int64_t sum = 0;
     for (int k = 0; k < SCAN_PER_THREAD; k++) {
@@ -2278,7 +2307,44 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(BatchArgs A, Worksp
         sum += c[k];
     }
     int64_t total;
-    int64_t run = W.scan_part[blockIdx.x] + block_excl_scan(sum, sh, tid, SCAN_THREADS, &total);
+    int64_t run = block_excl_scan(sum, sh, tid, SCAN_THREADS, &total);
+    unsigned long long* st = W.scan_state;
+    if (tid == 0 && blk > 0)
+        __hip_atomic_store(&st[blk], SC_TOTAL | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {  // the first wavefront looks back, 64 predecessors per round trip, nearest first
+        const int lane = tid;
+        int64_t excl = 0;
+        bool found = blk == 0;
+        for (int64_t hi = blk - 1; !found; hi -= 64) {
+            unsigned long long v;
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t p = hi - lane;
+                v = SC_PREFIX;  // before block 0: an empty prefix
+                if (p >= 0) v = __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((v & SC_MASK) != 0)) break;
+                if (++spins > (1u << 22)) {  // seconds: the dispatch-order premise does not hold; fail loudly
+                    raise(A.err, HUTK_E_DEVICE);
+                    v = SC_PREFIX;
+                    break;
+                }
+            }
+            const unsigned long long has_prefix = __ballot((v & SC_MASK) == SC_PREFIX);
+            const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 63;  // up to and including the nearest prefix
+            int64_t part = (lane <= stop) ? (int64_t)(v & ~SC_MASK) : 0;
+            for (int o = 32; o; o >>= 1) part += __shfl_xor(part, o, 64);
+            excl += part;
+            found = has_prefix != 0;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&st[blk], SC_PREFIX | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            s_base = excl;
+            if (blk == (int64_t)gridDim.x - 1) W.tile_base[A.n_tiles] = excl + total;
+        }
+    }
+    __syncthreads();
+    run += s_base;
     for (int k = 0; k < SCAN_PER_THREAD; k++) {
         if (base + k < A.n_tiles) W.tile_base[base + k] = run;
         run += c[k];
@@ -2296,9 +2362,9 @@ constexpr int GATHER_THREADS = 64;
 // was bound by workgroup dispatch, not by memory.
 constexpr int GATHER_TILES = 4, GATHER_WAVES = 4, GATHER_UNROLL = 5;
 template <typename RunT>
-__global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(DevTables T, BatchArgs A, Workspace W) {
+__device__ __forceinline__ void d_gather(const DevTables& T, const BatchArgs& A, const Workspace& W, int64_t vblock) {
     const int lane = threadIdx.x & 63;
-    const int64_t first = ((int64_t)blockIdx.x * GATHER_WAVES + (threadIdx.x >> 6)) * GATHER_TILES;
+    const int64_t first = (vblock * GATHER_WAVES + (threadIdx.x >> 6)) * GATHER_TILES;
     // everything is issued before anything is consumed: the metadata of all tiles, then up to
     // GATHER_UNROLL x 64 symbols of each tile (a tile has ~250), then the stores
     int64_t base[GATHER_TILES];
@@ -2339,13 +2405,14 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_gather(DevTables T, Batch
 }
 
 // Tiles with exception words, from the list k_tiles made: their ids are interleaved with the dense run.
-__global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, BatchArgs A, Workspace W) {
+__device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                             uint32_t vgrid) {
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     __shared__ int64_t e_tok[GATHER_EXC_LDS];
     const int tid = threadIdx.x;
     const uint32_t n_list = W.counters[1];
-    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+    for (uint32_t li = vblock; li < n_list; li += vgrid) {
     const int64_t tile = W.exc_tiles[li];
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
@@ -2358,7 +2425,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
         continue;
     }
-    __syncthreads();  // the LDS arrays are reused from the previous tile
+    wave_sync();  // the LDS arrays are reused from the previous tile (one wavefront runs this: LDS order is enough)
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
     // positions and id counts of the tile's exception words, one record per lane (all loads in flight
     // together), then the running sum of the counts over LDS
@@ -2367,7 +2434,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
         e_cum[e + 1] = recs[e].tok_base < 0 ? 0u : recs[e].cnt;  // (a word that was too large has no ids)
         e_tok[e] = recs[e].tok_base;
     }
-    __syncthreads();
+    wave_sync();
     if (tid == 0) {
         uint32_t acc = 0;
         e_cum[0] = 0;
@@ -2376,7 +2443,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
             e_cum[e] = acc;
         }
     }
-    __syncthreads();
+    wave_sync();
     for (uint32_t k = tid; k < dense; k += GATHER_THREADS) {
         // exceptions that come before dense id k: those with wpos <= k
         uint32_t lo = 0, hi = nexc;
@@ -2405,8 +2472,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void k_gather_exc(DevTables T, Batc
 // ------------------------------------------------------------------------
 // k_doc_off: out_offsets[d] for d in [0, n_docs]
 // ------------------------------------------------------------------------
-__global__ void k_doc_off(BatchArgs A, Workspace W) {
-    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void d_doc_off(const BatchArgs& A, const Workspace& W, int64_t vblock) {
+    const int64_t d = vblock * blockDim.x + threadIdx.x;
     if (d > A.n_docs) return;
     const int64_t o = A.offsets[d];
     if (o >= A.n_bytes) {
@@ -2422,6 +2489,23 @@ __global__ void k_doc_off(BatchArgs A, Workspace W) {
             if (recs[e].ws < o) v += recs[e].cnt;
     }
     A.out_offsets[d] = v;
+}
+
+
+// k_finish: everything behind the scan in ONE launch -- the workgroups [0, g_gather) copy tile runs to ids_out,
+// [g_gather, g_gather + g_exc) do the same for the tiles that also hold exception words, the rest write out_offsets.
+constexpr int FINISH_EXC_BLOCKS = 1024;
+template <typename RunT>
+__global__ __launch_bounds__(64 * GATHER_WAVES) void k_finish(DevTables T, BatchArgs A, Workspace W, uint32_t g_gather) {
+    const uint32_t b = blockIdx.x;
+    if (b < g_gather) {
+        d_gather<RunT>(T, A, W, b);
+    } else if (b < g_gather + FINISH_EXC_BLOCKS) {
+        if (threadIdx.x < GATHER_THREADS && W.counters[1] != 0)  // (a workgroup's first wavefront; uniform per wavefront)
+            d_gather_exc(T, A, W, b - g_gather, FINISH_EXC_BLOCKS);
+    } else {
+        d_doc_off(A, W, (int64_t)(b - g_gather - FINISH_EXC_BLOCKS));
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -2465,28 +2549,22 @@ void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     hipLaunchKernelGGL(k_compact, dim3((unsigned)((a.n_tiles + CP_WAVES - 1) / CP_WAVES)), dim3(64 * CP_WAVES), 0, s, a, w);
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    // fixed grid; every wavefront pulls records until the device counter runs out
-    // words of at most 63 bytes, 64 per wavefront
-    if (t.sym16) hipLaunchKernelGGL(k_exc_medium<uint16_t>, dim3(2560), dim3(64), 0, s, t, a, w);
-    else hipLaunchKernelGGL(k_exc_medium<uint32_t>, dim3(1280), dim3(64), 0, s, t, a, w);
-    // longer words: their ends first, then four per wavefront up to 256 units (byte mode), the rest one per wavefront
-    hipLaunchKernelGGL(k_exc<true>, dim3(4096), dim3(64), 0, s, t, a, w);
-    hipLaunchKernelGGL(k_exc_split, dim3(1024), dim3(64), 0, s, w);
-    hipLaunchKernelGGL(k_exc_quad, dim3(5120), dim3(64), 0, s, t, a, w);  // its list is empty outside byte mode
-    hipLaunchKernelGGL(k_exc<false>, dim3(4096), dim3(64), 0, s, t, a, w);
+    // two launches, fixed grids; every wavefront pulls work until its device list runs out
+    if (t.sym16) hipLaunchKernelGGL(k_exc_a<uint16_t>, dim3(EXA_MEDIUM16 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM16);
+    else hipLaunchKernelGGL(k_exc_a<uint32_t>, dim3(EXA_MEDIUM32 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM32);
+    hipLaunchKernelGGL(k_exc_b, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    const int64_t nb = (a.n_tiles + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
-    hipLaunchKernelGGL(k_scan_parts, dim3(1), dim3(1024), 0, s, a, w, nb);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, a, w);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)w.n_scan_blocks), dim3(SCAN_THREADS), 0, s, a, w);
 }
-void launch_gather(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+int64_t scan_blocks(int64_t n_tiles) { return (n_tiles + SCAN_BLOCK - 1) / SCAN_BLOCK; }
+void launch_finish(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const int64_t per_wg = (int64_t)GATHER_TILES * GATHER_WAVES;
-    const dim3 g((unsigned)((a.n_tiles + per_wg - 1) / per_wg)), b(64 * GATHER_WAVES);
-    if (t.sym16) hipLaunchKernelGGL(k_gather<uint16_t>, g, b, 0, s, t, a, w);
-    else hipLaunchKernelGGL(k_gather<uint32_t>, g, b, 0, s, t, a, w);
-    hipLaunchKernelGGL(k_gather_exc, dim3(1024), dim3(GATHER_THREADS), 0, s, t, a, w);
+    const unsigned g_gather = (unsigned)((a.n_tiles + per_wg - 1) / per_wg);
+    const unsigned g_doc = (unsigned)((a.n_docs + 1 + 64 * GATHER_WAVES - 1) / (64 * GATHER_WAVES));
+    const dim3 g(g_gather + FINISH_EXC_BLOCKS + g_doc), b(64 * GATHER_WAVES);
+    if (t.sym16) hipLaunchKernelGGL(k_finish<uint16_t>, g, b, 0, s, t, a, w, g_gather);
+    else hipLaunchKernelGGL(k_finish<uint32_t>, g, b, 0, s, t, a, w, g_gather);
 }
 // chunked host path (hutk_api.cpp): document offsets of a chunk made relative to its first byte, and the
 // chunk's out_offsets made absolute by the ids of the chunks before it (a device scalar)
@@ -2508,10 +2586,6 @@ void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s) {
     hipLaunchKernelGGL(k_copy_one, dim3(1), dim3(1), 0, s, base, v + (n - 1));
 }
 
-void launch_doc_offsets(const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    const unsigned g = (unsigned)((a.n_docs + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_doc_off, dim3(g), dim3(256), 0, s, a, w);
-}
 void launch_bpe_symbols(const DevTables& t, uint32_t* d_syms, int n, int32_t* d_ids_out,
                         int32_t* d_n_out, hipStream_t s) {
     hipLaunchKernelGGL(k_bpe_symbols, dim3(1), dim3(64), 0, s, t, d_syms, n, d_ids_out, d_n_out);
