@@ -603,9 +603,13 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     launch_tiles(c->dt, A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     launch_merge(c->dt, A, W, s);  // (before the exception kernels: it sets a tile's id count, they add to it)
-    launch_exceptions(c->dt, A, W, s);
-    launch_scan(A, W, s);
-    launch_finish(c->dt, A, W, s);
+    if (small_tail(A)) {
+        launch_tail_small(c->dt, A, W, s);
+    } else {
+        launch_exceptions(c->dt, A, W, s);
+        launch_scan(A, W, s);
+        launch_finish(c->dt, A, W, s);
+    }
     HIP_TRY(hipGetLastError());
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev[3], s));

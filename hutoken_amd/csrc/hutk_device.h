@@ -163,6 +163,9 @@ bool tiles_defer(const DevTables& t);  // k_tiles leaves the merge loop to k_mer
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
 int64_t scan_blocks(int64_t n_tiles);
+// a batch of a few tiles: exception stages, scan and copy-out as one single-wavefront launch
+bool small_tail(const BatchArgs& a);
+void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // tile runs (+ exception words) -> ids_out, out_offsets: one launch
 void launch_finish(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // one-off at context creation: merge a symbol sequence on the device, return ids

@@ -2362,9 +2362,9 @@ constexpr int GATHER_THREADS = 64;
 // was bound by workgroup dispatch, not by memory.
 constexpr int GATHER_TILES = 4, GATHER_WAVES = 4, GATHER_UNROLL = 5;
 template <typename RunT>
-__device__ __forceinline__ void d_gather(const DevTables& T, const BatchArgs& A, const Workspace& W, int64_t vblock) {
+__device__ __forceinline__ void d_gather(const DevTables& T, const BatchArgs& A, const Workspace& W, int64_t vwave) {
     const int lane = threadIdx.x & 63;
-    const int64_t first = (vblock * GATHER_WAVES + (threadIdx.x >> 6)) * GATHER_TILES;
+    const int64_t first = vwave * GATHER_TILES;  // vwave: index of this wavefront among all that gather
     // everything is issued before anything is consumed: the metadata of all tiles, then up to
     // GATHER_UNROLL x 64 symbols of each tile (a tile has ~250), then the stores
     int64_t base[GATHER_TILES];
@@ -2499,13 +2499,51 @@ template <typename RunT>
 __global__ __launch_bounds__(64 * GATHER_WAVES) void k_finish(DevTables T, BatchArgs A, Workspace W, uint32_t g_gather) {
     const uint32_t b = blockIdx.x;
     if (b < g_gather) {
-        d_gather<RunT>(T, A, W, b);
+        d_gather<RunT>(T, A, W, (int64_t)b * GATHER_WAVES + (threadIdx.x >> 6));
     } else if (b < g_gather + FINISH_EXC_BLOCKS) {
         if (threadIdx.x < GATHER_THREADS && W.counters[1] != 0)  // (a workgroup's first wavefront; uniform per wavefront)
             d_gather_exc(T, A, W, b - g_gather, FINISH_EXC_BLOCKS);
     } else {
         d_doc_off(A, W, (int64_t)(b - g_gather - FINISH_EXC_BLOCKS));
     }
+}
+
+// k_tail_small: everything behind k_tiles for a batch of a few tiles (a sentence, a handful of documents), where the
+// launches themselves are the cost: ONE wavefront runs the exception stages, the scan and the copy-out one after the
+// other.  Between stages an agent-scope fence makes the wavefront's own global writes visible to its later loads.
+constexpr int SMALL_TILES = 32;
+template <typename SymT>
+__global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Workspace W) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds)),
+                                                             cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4))];
+    const int lane = threadIdx.x;
+    auto stage_done = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __syncthreads();
+    };
+    if (W.counters[0] != 0) {  // exception words
+        d_exc_medium<SymT>(T, A, W, 0, 1, lds);
+        stage_done();
+        for (uint32_t sub = 0; sub < ENDS_SHARE; sub++) d_exc_ends(T, A, W, sub, ENDS_SHARE, lds);
+        stage_done();
+        d_exc_quad(T, A, W, 0, 1, lds);
+        stage_done();
+        d_exc(T, A, W, 0, 1, lds);
+        stage_done();
+    }
+    // exclusive scan of the tiles' id counts (at most SMALL_TILES <= 64)
+    {
+        uint32_t total;
+        const uint32_t mine = lane < A.n_tiles ? W.tile_count[lane] : 0u;
+        const uint32_t before = wave_excl_scan(mine, lane, &total);
+        if (lane < A.n_tiles) W.tile_base[lane] = before;
+        if (lane == 0) W.tile_base[A.n_tiles] = total;
+    }
+    stage_done();
+    for (int64_t w = 0; w * GATHER_TILES < A.n_tiles; w++) d_gather<SymT>(T, A, W, w);
+    if (W.counters[1] != 0) d_gather_exc(T, A, W, 0, 1);
+    stage_done();  // (d_gather_exc writes the exception records' output positions; nothing below reads them, but keep the stages uniform)
+    for (int64_t vb = 0; vb * 64 <= A.n_docs; vb++) d_doc_off(A, W, vb);
 }
 
 // ------------------------------------------------------------------------
@@ -2547,6 +2585,11 @@ void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     if (!tiles_defer(t)) return;
     hipLaunchKernelGGL(k_merge, dim3((unsigned)((a.n_tiles + MG_TILES - 1) / MG_TILES)), dim3(64), 0, s, t, a, w);
     hipLaunchKernelGGL(k_compact, dim3((unsigned)((a.n_tiles + CP_WAVES - 1) / CP_WAVES)), dim3(64 * CP_WAVES), 0, s, a, w);
+}
+bool small_tail(const BatchArgs& a) { return a.n_tiles <= SMALL_TILES && a.n_docs <= 4096; }
+void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+    if (t.sym16) hipLaunchKernelGGL(k_tail_small<uint16_t>, dim3(1), dim3(64), 0, s, t, a, w);
+    else hipLaunchKernelGGL(k_tail_small<uint32_t>, dim3(1), dim3(64), 0, s, t, a, w);
 }
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     // two launches, fixed grids; every wavefront pulls work until its device list runs out
