@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -46,7 +47,10 @@ struct DevBuf {
     size_t cap = 0;  // elements
     hipError_t reserve(size_t n) {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipDeviceSynchronize();  // an earlier asynchronous call may still be using the old allocation
+            (void)hipFree(p);
+        }
         p = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 64;
@@ -125,6 +129,12 @@ struct hutk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    // One workspace per context: calls on a context are SERIALISED.  The mutex orders the host side (calls from several
+    // threads), the event orders the device side: every asynchronous call records it when its last kernel is enqueued,
+    // and the next call's stream waits for it before its first kernel -- whatever streams the two calls run on.
+    std::recursive_mutex mu;
+    hipEvent_t ev_busy = nullptr;
+    bool busy_valid = false;
 };
 
 namespace {
@@ -356,6 +366,7 @@ void destroy(hutk_ctx* c) {
         if (c->pipe.s_out) (void)hipStreamDestroy(c->pipe.s_out);
         for (auto& e : c->ev)
             if (e) (void)hipEventDestroy(e);
+        if (c->ev_busy) (void)hipEventDestroy(c->ev_busy);
         if (c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -470,6 +481,7 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
         }
         bool ok = true;
         for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&c->ev_busy, hipEventDisableTiming) == hipSuccess;
         if (!ok) { rc = set_err(HUTK_E_DEVICE, "hipEventCreate failed"); break; }
         rc = upload_tables(c);
         if (rc == HUTK_OK && !getenv("HUTK_NO_WORD_TABLE")) rc = build_word_table(c);
@@ -563,8 +575,14 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     if (((uintptr_t)d_bytes & 15u) != 0) return set_err(HUTK_E_ARG, "d_bytes must be 16-byte aligned");
     if (ids_cap < hutk_ids_capacity(c, n_bytes, n_docs) - 1)
         return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(s, c->ev_busy, 0));  // the previous call still owns the workspace
+    struct BusyMark {  // recorded on every way out, behind whatever this call enqueued
+        hutk_ctx* c; hipStream_t s;
+        ~BusyMark() { if (hipEventRecord(c->ev_busy, s) == hipSuccess) c->busy_valid = true; }
+    } busy_mark{c, s};
     const int64_t n_tiles = (n_bytes + TILE_BYTES - 1) / TILE_BYTES;
     if (n_tiles > 0x7FFFFFFFll) return set_err(HUTK_E_ARG, "batch too large");
     Workspace W{};
@@ -726,6 +744,8 @@ int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
 
 int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                       int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);  // (the staging buffers are the context's too)
     if (c && !c->host_only && !c->pattern.empty())
         return encode_batch_regex(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
     if (c && !c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
@@ -744,8 +764,14 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to decode on");
     if (n_docs < 0 || n_ids < 0 || !d_id_offsets || !d_out_offsets || (n_ids > 0 && !d_ids))
         return set_err(HUTK_E_ARG, "bad argument");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(s, c->ev_busy, 0));
+    struct BusyMark {
+        hutk_ctx* c; hipStream_t s;
+        ~BusyMark() { if (hipEventRecord(c->ev_busy, s) == hipSuccess) c->busy_valid = true; }
+    } busy_mark{c, s};
     const int64_t tile = dec_tile_ids();
     const int64_t n_tiles = (n_ids + tile - 1) / tile;
     if (n_tiles > 0x7FFFFFFFll) return set_err(HUTK_E_ARG, "batch too large");
@@ -786,6 +812,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
 int hutk_decode_batch(hutk_ctx* c, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs, uint8_t* bytes_out,
                       int64_t bytes_cap, int64_t* out_offsets, int32_t* status) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to decode on");
     if (n_docs < 0 || !id_offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
     if (id_offsets[0] != 0) return set_err(HUTK_E_ARG, "id_offsets[0] must be 0");

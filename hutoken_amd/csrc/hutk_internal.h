@@ -115,6 +115,9 @@ HUTK_HD uint32_t char_hash(uint32_t packed) {
     h ^= h >> 16;
     return h * 0x85EBCA6Bu;
 }
+// the two candidate slots of a character: the top bits of its hash, and an odd multiple of its low bits away from them
+HUTK_HD uint32_t char_slot1(uint32_t h, uint32_t shift) { return h >> shift; }
+HUTK_HD uint32_t char_slot2(uint32_t h, uint32_t mask) { return ((h >> 7) ^ ((h & 0x7Fu) * 0x2F1Bu) ^ 0x5A5Au) & mask; }
 
 // reference limit: 64 * word length must fit the 16 MiB arena (core.c:27-28, 402-407)
 constexpr int64_t MAX_WORD_BYTES = 262144;

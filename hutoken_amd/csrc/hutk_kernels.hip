@@ -80,13 +80,11 @@ __device__ __forceinline__ uint32_t pair_lookup(const DevTables& T, uint32_t l, 
 }
 
 __device__ __forceinline__ uint32_t char_lookup(const DevTables& T, uint32_t packed) {
-    uint32_t h = char_hash(packed) >> T.char_shift;
-    for (;;) {
-        const uint64_t s = T.char_slots[h];
-        if ((uint32_t)(s >> 32) == packed) return (uint32_t)s;
-        if (s == SLOT_EMPTY) return SYM_UNK;
-        h = (h + 1) & T.char_mask;
-    }
+    // two-choice cuckoo: both candidate slots loaded together, no dependent probe sequence
+    const uint32_t h = char_hash(packed);
+    const uint64_t a = T.char_slots[char_slot1(h, T.char_shift)], b = T.char_slots[char_slot2(h, T.char_mask)];
+    const uint32_t ka = (uint32_t)(a >> 32) ^ packed, kb = (uint32_t)(b >> 32) ^ packed;  // (bitwise: see pair_match)
+    return ka == 0 ? (uint32_t)a : kb == 0 ? (uint32_t)b : SYM_UNK;
 }
 
 // rank used for comparisons (smaller merges first; ties resolved by position)
@@ -2435,13 +2433,17 @@ __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs
         e_tok[e] = recs[e].tok_base;
     }
     wave_sync();
-    if (tid == 0) {
-        uint32_t acc = 0;
-        e_cum[0] = 0;
-        for (uint32_t e = 1; e <= nexc; e++) {
-            acc += e_cum[e];
-            e_cum[e] = acc;
+    {   // running sum of the counts, 64 at a time (a tile of long-word text has hundreds of them)
+        uint32_t carry = 0;
+        for (uint32_t e0 = 0; e0 < nexc; e0 += GATHER_THREADS) {
+            const uint32_t e = e0 + tid;
+            const uint32_t v = e < nexc ? e_cum[e + 1] : 0u;
+            uint32_t tot;
+            const uint32_t before = wave_excl_scan(v, tid, &tot);
+            if (e < nexc) e_cum[e + 1] = carry + before + v;
+            carry += tot;
         }
+        if (tid == 0) e_cum[0] = 0;
     }
     wave_sync();
     for (uint32_t k = tid; k < dense; k += GATHER_THREADS) {

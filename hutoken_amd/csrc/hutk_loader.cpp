@@ -308,16 +308,25 @@ void finish_char_table(Tables& T, std::vector<std::pair<uint32_t, uint32_t>>& ch
         T.char_shift = 28;
         return;
     }
-    uint32_t cap = pow2_at_least(chars.size() * 2 + 16);
-    uint32_t lg = 0;
-    while ((1u << lg) < cap) lg++;
-    T.char_mask = cap - 1;
-    T.char_shift = 32 - lg;
-    T.char_slots.assign(cap, SLOT_EMPTY);
-    for (auto& c : chars) {
-        uint32_t h = char_hash(c.first) >> T.char_shift;
-        while (T.char_slots[h] != SLOT_EMPTY) h = (h + 1) & T.char_mask;
-        T.char_slots[h] = ((uint64_t)c.first << 32) | c.second;
+    // two-choice cuckoo like the other tables: slot char_slot1(h) or char_slot2(h), both loaded together by a lookup, no
+    // dependent probe sequence (a wavefront pays for the slowest of its 64 lanes)
+    uint32_t cap = pow2_at_least(chars.size() * 5 / 2 + 16);
+    for (int attempt = 0;; attempt++) {
+        uint32_t lg = 0;
+        while ((1u << lg) < cap) lg++;
+        T.char_mask = cap - 1;
+        T.char_shift = 32 - lg;
+        std::vector<uint32_t> where;
+        const bool ok = cuckoo_place(chars.size(), cap,
+                                     [&](uint32_t i) { return char_slot1(char_hash(chars[i].first), T.char_shift); },
+                                     [&](uint32_t i) { return char_slot2(char_hash(chars[i].first), T.char_mask); }, where);
+        if (ok || attempt == 6) {
+            T.char_slots.assign(cap, SLOT_EMPTY);
+            for (size_t i = 0; i < chars.size(); i++)
+                if (where[i] != 0xFFFFFFFFu) T.char_slots[where[i]] = ((uint64_t)chars[i].first << 32) | chars[i].second;
+            break;  // (a character left out after seven doublings would read as unknown: cannot happen at this load)
+        }
+        cap *= 2;
     }
 }
 

@@ -112,6 +112,14 @@ int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offset
                       int64_t n_docs, int32_t* ids_out, int64_t ids_cap,
                       int64_t* out_offsets, int32_t* status);
 
+/* THREADS AND STREAMS.  A context owns one workspace (tile metadata, symbol runs, exception lists), so the calls on one
+ * context are serialised: on the host by a mutex inside the context (any thread may call), on the device by an event --
+ * each asynchronous call records it behind its last kernel and the next call makes its stream wait for it before its
+ * first kernel, whichever streams the two calls use.  Nothing races and nothing is freed under a running kernel, but two
+ * calls on ONE context do not overlap; give every stream that should encode concurrently a context of its own (the
+ * tables are a few MB).  The reference's contexts are read-only and shared by its worker threads (taskqueue.h:16-25); its
+ * concurrency is inside one batch_encode call, as is this library's. */
+
 /* Same computation with every buffer already resident in device memory (the
  * form bench.py times and a GPU data loader would call).  n_bytes must equal
  * offsets[n_docs] (the host needs it to size the launch without a sync).

@@ -325,3 +325,53 @@ def test_python_surface(vg_files, oracle_mod):
     with pytest.raises(RuntimeError, match="embedded null character"):
         hutoken.encode("a\0b")
     assert hutoken.batch_encode(["ab\0cd"]) == [orc.encode("ab")]
+
+
+def test_two_streams_and_two_threads_on_one_context(vg_files, oracle_mod):
+    """Calls on one context are serialised (a mutex on the host, an event on the device): launches on two streams without
+    any synchronisation in between, and host calls from two threads, give the same ids as one call after the other."""
+    import threading
+    import torch
+    from hutoken_amd import _capi, synth
+    vp, sp, kw = vg_files
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    dev = torch.device("cuda", 0)
+    batches = []
+    for k, n in enumerate((6000, 900)):  # different sizes: the second call shrinks/grows what the first one uses
+        d, o = synth.corpus("C3", n, first_doc=50_000 * (k + 1))
+        want = orc.encode_packed(d, o, 8)
+        db, do = torch.from_numpy(d).to(dev), torch.from_numpy(o).to(dev)
+        cap = ctx.ids_capacity(len(d), n)
+        bufs = [(torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(n + 1, dtype=torch.int64, device=dev),
+                 torch.zeros(1, dtype=torch.int32, device=dev)) for _ in range(4)]
+        batches.append((d, o, n, db, do, cap, bufs, want, torch.cuda.Stream(dev)))
+    torch.cuda.synchronize(dev)
+    for rep in range(4):  # A on stream 1, B on stream 2, A, B, ... with nothing in between
+        for (d, o, n, db, do, cap, bufs, want, st) in batches:
+            ids, oo, err = bufs[rep]
+            ctx.encode_device(db.data_ptr(), do.data_ptr(), n, len(d), ids.data_ptr(), cap, oo.data_ptr(), 0, err.data_ptr(),
+                              st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    for (d, o, n, db, do, cap, bufs, want, st) in batches:
+        for ids, oo, err in bufs:
+            assert int(err.item()) == 0
+            got_oo = oo.cpu().numpy()
+            assert np.array_equal(got_oo, want[1])
+            assert np.array_equal(ids[: int(got_oo[-1])].cpu().numpy(), want[0])
+    # host entry point from two threads at once
+    results = {}
+
+    def work(k):
+        d, o = batches[k][0], batches[k][1]
+        for _ in range(3):
+            results[k] = ctx.encode_packed(d, o)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(2):
+        ids, oo, st, rc = results[k]
+        assert rc == 0 and np.array_equal(oo, batches[k][7][1]) and np.array_equal(ids, batches[k][7][0])
