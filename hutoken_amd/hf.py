@@ -66,74 +66,92 @@ def _merges_text(tok):
     return "\n".join(lines) + "\n"
 
 
-def export(model_or_path, **kwargs):
-    """Convert a Hugging Face tokenizer into huToken's files (hutoken.py:44-107).
-
-    Returns dict(vocab_file, special_chars_file, prefix, is_byte_encoder, merges_file_path, tokenizer)."""
+def _load(reference):
+    """The `transformers` tokenizer behind a model id or directory; the reference's error texts (hutoken.py:46-54)."""
     try:
         from transformers import AutoTokenizer
     except ImportError as e:  # the reference would fail with a NameError here (hutoken.py:4-7, 46)
         raise RuntimeError("hutoken: the Hugging Face branch of initialize() needs the 'transformers' "
                            f"package: {e}") from e
     try:
-        hf_tokenizer = AutoTokenizer.from_pretrained(model_or_path)
+        tok = AutoTokenizer.from_pretrained(reference)
     except (OSError, ValueError) as e:
         raise ValueError("Could not download Hugging Face tokenizer "
-                         f"'{model_or_path}': {e}")
-    if not hasattr(hf_tokenizer, "vocab"):
+                         f"'{reference}': {e}")
+    if not hasattr(tok, "vocab"):
         raise ValueError("Could not extract vocab from Hugging Face "
                          "tokenizer.")
+    return tok
 
-    cache_dir = os.getenv("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
-    parts = [p for p in str(model_or_path).replace("\\", "/").split("/") if p]
-    if len(parts) < 2:  # the reference unpacks exactly "<org>/<model>" (hutoken.py:58)
-        raise ValueError(f"not enough values to unpack (expected 2, got {len(parts)})")
-    org_name, model_name = parts[-2], parts[-1]
-    vocab_dir = os.path.join(cache_dir, f"hutoken/{org_name}/{model_name}")
-    os.makedirs(vocab_dir, exist_ok=True)
-    vocab_file = os.path.join(vocab_dir, f"{model_name}.txt")
-    hf_tokenizer.save_pretrained(vocab_dir)
 
+def _target(reference):
+    """-> (folder, stem): $XDG_CACHE_HOME/hutoken/<org>/<model>/ and <model>, the layout of hutoken.py:55-60."""
+    pieces = [x for x in str(reference).replace("\\", "/").split("/") if x]
+    if len(pieces) < 2:  # the reference unpacks exactly "<org>/<model>" (hutoken.py:58)
+        raise ValueError(f"not enough values to unpack (expected 2, got {len(pieces)})")
+    root = os.getenv("XDG_CACHE_HOME", os.path.join(os.path.expanduser("~"), ".cache"))
+    folder = os.path.join(root, "hutoken", pieces[-2], pieces[-1])
+    os.makedirs(folder, exist_ok=True)
+    return folder, pieces[-1]
+
+
+def _entries(tok):
+    """(token bytes, id) in id order; a token that has no UTF-8 form (a lone surrogate) is reported and left out."""
+    for token, idx in sorted(tok.vocab.items(), key=lambda kv: kv[1]):
+        try:
+            yield token.encode("utf-8"), idx
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write(f"Failed to process token '{token}': {e}")
+
+
+def _replacements(tok, byte_level):
+    """byte -> replacement string for the bytes of hutoken.py:15-20: the byte-level table when there is one, else what
+    the tokenizer itself makes of the character (hutoken.py:88-97)."""
+    table = getattr(tok, "byte_encoder", None) or (vf.bytes_to_unicode() if byte_level else None)
+    if table is not None:
+        return {b: table[b] for b in _SPECIAL_CHARS}
+    return {b: "".join(tok.tokenize(chr(b))) for b in _SPECIAL_CHARS}
+
+
+def _merges_file(tok, folder, reference):
+    """merges.txt as save_pretrained left it, or written from the backend model; None without merge rules."""
+    path = os.path.join(folder, "merges.txt")
+    if os.path.isfile(path):
+        return path
+    text = _merges_text(tok)
+    if text is None:
+        sys.stderr.write(f"No merges.txt found for '{reference}'. Continuing without merge rules.\n")
+        return None
+    with open(path, "w", encoding="utf-8", newline="") as f:
+        f.write(text)
+    return path
+
+
+def _written(path, what, write):
     try:
-        with open(vocab_file, "w", encoding="utf-8") as f:
-            for token, idx in sorted(hf_tokenizer.vocab.items(), key=lambda item: item[1]):
-                try:
-                    f.write(vf.hex_line(token.encode("utf-8"), idx))
-                except Exception as e:  # e.g. a lone surrogate in a token
-                    sys.stderr.write(f"Failed to process token '{token}': {e}")
+        write()
     except IOError as e:
         traceback.print_exc(file=sys.stderr)
-        raise IOError(f"Could not write vocab file to '{vocab_file}': {e}")
+        raise IOError(f"Could not write {what} to '{path}': {e}")
+    return path
 
-    hu_tokenized = hf_tokenizer.tokenize("hu")[0]
-    prefix = hu_tokenized[0] if hu_tokenized != "hu" else None
 
-    byte_level = is_byte_level(hf_tokenizer)
-    special_chars_file = os.path.join(vocab_dir, f"{model_name}_special_chars.txt")
-    try:
-        with open(special_chars_file, "w", encoding="utf-8") as f:
-            table = getattr(hf_tokenizer, "byte_encoder", None) or (vf.bytes_to_unicode() if byte_level else None)
-            for char in _SPECIAL_CHARS:
-                if table is not None:
-                    value = table[char]
-                else:
-                    value = "".join(hf_tokenizer.tokenize(chr(char)))
-                f.write(f"{char} == {value}\n")
-    except IOError as e:
-        traceback.print_exc(file=sys.stderr)
-        raise IOError("Could not write special characters file to "
-                      f"'{special_chars_file}': {e}")
+def export(reference, **options):
+    """Convert a Hugging Face tokenizer into huToken's files (what hutoken.py:44-107 does inline).
 
-    merges_file_path = os.path.join(vocab_dir, "merges.txt")
-    if not os.path.isfile(merges_file_path):
-        text = _merges_text(hf_tokenizer)
-        if text is not None:
-            with open(merges_file_path, "w", encoding="utf-8", newline="") as f:
-                f.write(text)
-        else:
-            merges_file_path = None
-            sys.stderr.write(f"No merges.txt found for '{model_or_path}'. Continuing without merge rules.\n")
-
-    is_byte_encoder = 1 if byte_level else kwargs.get("is_byte_encoder", 0)
-    return dict(vocab_file=vocab_file, special_chars_file=special_chars_file, prefix=prefix,
-                is_byte_encoder=is_byte_encoder, merges_file_path=merges_file_path, tokenizer=hf_tokenizer)
+    Returns dict(vocab_file, special_chars_file, prefix, is_byte_encoder, merges_file_path, tokenizer)."""
+    tok = _load(reference)
+    folder, stem = _target(reference)
+    tok.save_pretrained(folder)
+    byte_level = is_byte_level(tok)
+    vocab_path = os.path.join(folder, f"{stem}.txt")
+    special_path = os.path.join(folder, f"{stem}_special_chars.txt")
+    _written(vocab_path, "vocab file", lambda: vf.write_vocab_file(vocab_path, _entries(tok), encoding="utf-8"))
+    _written(special_path, "special characters file",
+             lambda: vf.write_special_file(special_path, _replacements(tok, byte_level)))
+    # the marker a tokenizer puts in front of a word ("hu" -> "\u2581hu"): huToken's prefix (hutoken.py:75-76)
+    first_piece = tok.tokenize("hu")[0]
+    return dict(vocab_file=vocab_path, special_chars_file=special_path,
+                prefix=None if first_piece == "hu" else first_piece[0],
+                is_byte_encoder=1 if byte_level else options.get("is_byte_encoder", 0),
+                merges_file_path=_merges_file(tok, folder, reference), tokenizer=tok)

@@ -44,9 +44,9 @@ def hex_line(token: bytes, idx: int) -> str:
     return "".join("0x%02X" % b for b in token) + " == %d\n" % idx
 
 
-def write_vocab_file(path, entries):
+def write_vocab_file(path, entries, encoding="ascii"):
     """entries: iterable of (token bytes, id)."""
-    with open(path, "w", encoding="ascii") as f:
+    with open(path, "w", encoding=encoding) as f:
         for tok, idx in entries:
             f.write(hex_line(tok, idx))
 
