@@ -206,7 +206,7 @@ int upload_tables(hutk_ctx* c) {
     D.rank_is_sym = T.rank_is_sym;
     D.ident_ids = T.ident_ids;
     D.sym16 = T.sym16;
-    D.split_merge = getenv("HUTK_SPLIT_MERGE") && atoi(getenv("HUTK_SPLIT_MERGE")) ? 1 : 0;
+    D.split_merge = getenv("HUTK_SPLIT_MERGE") ? atoi(getenv("HUTK_SPLIT_MERGE")) : 0;  // 0 none, 1 all, 2 / 3: words over 16 / 12 units
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
     D.word_tab = nullptr;
     D.word_mask = 0;

@@ -267,9 +267,6 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //   HUTK_LDS_TIGHT    1: pool and merge array sized so that 8 workgroups fit a CU's LDS; 0: roomier (7)
 //   HUTK_SPLIT_SWAR   1: classify with the SWAR mask algebra instead of the automaton
 //   HUTK_FAST_MERGE   0: the general merge loop also where the short form (packed keys) applies
-//   HUTK_POOL_SORT    1: the merge pool sorted by unit count (counting sort) instead of two classes (more than 8 units /
-//                     the rest); measured with 8 tiles per workgroup: -2.5 %, the two extra passes cost more than the
-//                     more even chunks return
 //   HUTK_STAGE_RUN    1: a tile's symbols go to HBM through LDS as 16-byte stores instead of lane by lane (measured: -1 %)
 //   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
 // ------------------------------------------------------------------------
@@ -338,7 +335,10 @@ struct TileLds {
     uint32_t arena_used, extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
 };
 
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, bool SPLIT = false>
+// KEEP: the merge loop runs in this kernel for words of up to KEEP units (pooled per workgroup); longer ones are left to
+// k_merge.  LANE_MAX_UNITS: everything here (the default); 1: everything in k_merge; in between: only the long tail,
+// which is what a workgroup's closing barrier otherwise waits for.
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, int KEEP = LANE_MAX_UNITS>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
@@ -354,21 +354,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #ifndef HUTK_STAGE_RUN
 #define HUTK_STAGE_RUN 0
 #endif
-#ifndef HUTK_POOL_SORT
-#define HUTK_POOL_SORT 0
-#endif
     // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
     constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
     // ... and then the merge loop is not run here at all: a word that needs it RESERVES one slot per unit in the
     // tile's run, leaves its start and unit count in the first two, and k_merge fills the slots in (see there)
-    constexpr bool DEFER = FAST && SPLIT;
-    static_assert(FAST || !SPLIT, "k_merge is the short form of the merge loop");
+    constexpr bool DEFER = FAST && KEEP < LANE_MAX_UNITS;
+    static_assert(FAST || KEEP == LANE_MAX_UNITS, "k_merge is the short form of the merge loop");
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
-#if HUTK_POOL_SORT
-    __shared__ uint32_t pool_hist[33], pool_rank[33], pool_start[33];  // merge words by unit count; placed so far; first pool entry of that count
-    constexpr uint32_t POOL_EMPTY = 0xFFFFFFFFu;
-#endif
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
@@ -716,59 +709,23 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_ABLATE_MERGE
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
 #endif
-    if constexpr (!DEFER)
+    if constexpr (KEEP > 1)
     for (;;) {
-#if HUTK_POOL_SORT
-        // The pool is SORTED by unit count, longest words first (a counting sort: histogram, scan, cursors), so that
-        // the 64 words of a chunk need about the same number of trips and the long tail sits in the first chunk only.
-        if (threadIdx.x < 33) { pool_hist[threadIdx.x] = 0; pool_rank[threadIdx.x] = 0; }
-        if (threadIdx.x == 0) pool_cnt[2] = 0;
-        __syncthreads();  // (also: every wavefront is done with the splitter tables that share the pool's LDS)
-        for (int i = threadIdx.x; i < POOL_CAP; i += 64 * WAVES) pool[i] = POOL_EMPTY;
-        uint32_t pending = 0;
-        if (tile_ok) {
-            pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
-            for (uint32_t m = pending; m; m &= m - 1)
-                atomicAdd(&pool_hist[word_units(me, 16 * lane + __builtin_ctz(m))], 1u);
-        }
-        __syncthreads();
-        uint32_t n_pool;
-        {   // lane i <-> words of 32 - i units: where their stretch of the pool begins.  Every wavefront computes and
-            // stores the same values (a shuffle inside the divergent loop below would read inactive lanes).
-            const uint32_t start = wave_excl_scan(lane <= 30 ? pool_hist[32 - lane] : 0u, lane, &n_pool);
-            if (lane <= 30) pool_start[32 - lane] = start;
-            wave_sync();
-            if (tile_ok) {
-                for (uint32_t m = pending; m; m &= m - 1) {
-                    const int j = __builtin_ctz(m);
-                    const int ws = 16 * lane + j;
-                    const int n = word_units(me, ws);
-                    const uint32_t idx = pool_start[n] + atomicAdd(&pool_rank[n], 1u);
-                    if (idx >= (uint32_t)POOL_CAP) continue;  // the shortest words wait for the next epoch
-                    const uint32_t moff = atomicAdd(&pool_cnt[2], (uint32_t)n);
-                    if (moff + n > (uint32_t)M_ARENA) continue;  // no room in m this epoch: the entry stays empty
-                    pool[idx] = (moff << 16) | (uint32_t)((wv << 10) | ws);
-                    pending &= ~(1u << j);
-                }
-                reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)pending;
-            }
-        }
-        __syncthreads();
-        n_pool = min(n_pool, (uint32_t)POOL_CAP);
-        for (uint32_t base = 64u * wv; base < n_pool; base += 64u * WAVES) {
-            const uint32_t wi = base + lane;
-            const uint32_t entry = wi < n_pool ? pool[wi] : POOL_EMPTY;
-            bool have = entry != POOL_EMPTY;
-#else
         if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
         __syncthreads();
         uint32_t pending = 0;
         if (tile_ok) {
             pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
+            uint32_t later = 0;  // words of more than KEEP units: they stay marked in mergem for the epilogue and k_merge
             for (uint32_t m = pending; m; m &= m - 1) {
                 const int j = __builtin_ctz(m);
                 const int ws = 16 * lane + j;
                 const int n = word_units(me, ws);
+                if (DEFER && n > KEEP) {
+                    later |= 1u << j;
+                    pending &= ~(1u << j);
+                    continue;
+                }
                 const bool is_long = n > POOL_LONG;
                 const uint32_t moff = atomicAdd(&pool_cnt[2], (uint32_t)n);
                 if (moff + n > (uint32_t)M_ARENA) continue;  // no room in m this epoch
@@ -778,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     pending &= ~(1u << j);
                 }
             }
-            reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)pending;
+            reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)(pending | later);
         }
         __syncthreads();
         const uint32_t n_long = min(pool_cnt[0], (uint32_t)POOL_LONG_CAP);
@@ -787,7 +744,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             const uint32_t wi = base + lane;
             bool have = wi < n_pool;
             const uint32_t entry = have ? (wi < n_long ? pool[wi] : pool[POOL_CAP - 1 - (wi - n_long)]) : 0u;
-#endif
             Tile& X = L[(entry >> 10) & 63u];  // the word's tile
             const int ws = entry & 1023;
             SymT* Sw = X.S + ws;
@@ -2563,9 +2519,11 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), dim3(64 * WV), 0, s, \
                        t, a, w)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
-    if (tiles_defer(t)) {  // the merge loop in k_merge instead (DevTables::split_merge)
-        hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, true>),
-                           dim3((unsigned)(((a.n_tiles + TILE_WAVES - 1) / TILE_WAVES + 7) / 8 * 8)), dim3(64 * TILE_WAVES), 0, s, t, a, w);
+    if (tiles_defer(t)) {  // the merge loop, or its long tail, in k_merge (DevTables::split_merge)
+        const dim3 g((unsigned)(((a.n_tiles + TILE_WAVES - 1) / TILE_WAVES + 7) / 8 * 8)), b(64 * TILE_WAVES);
+        if (t.split_merge == 1) hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 1>), g, b, 0, s, t, a, w);
+        else if (t.split_merge == 2) hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 16>), g, b, 0, s, t, a, w);
+        else hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 12>), g, b, 0, s, t, a, w);
         return;
     }
     switch (variant) {
