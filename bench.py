@@ -225,6 +225,38 @@ def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
                              "docs": n_docs, "verified_vs_oracle": ok,
                              "note": "hutk_encode_batch, page-locked host bytes+offsets in, host ids+offsets out "
                                      "(hutk_host_alloc); chunks of whole documents, H2D / kernels / D2H overlapped"}}
+    # every GPU this process sees behind ONE context (hutk_ctx_add_device): only where there is more than one, and never
+    # under torchrun (there each rank has its own GPU)
+    try:
+        import torch
+        n_vis = torch.cuda.device_count() if int(os.environ.get("WORLD_SIZE", "1")) == 1 else 1
+        if os.environ.get("HUTK_BENCH_SAME_DEVICE_TWICE"):  # rehearsal on a one-GPU box
+            n_vis = 2
+        if n_vis > 1:
+            others = [dev_index] * (n_vis - 1) if os.environ.get("HUTK_BENCH_SAME_DEVICE_TWICE") else \
+                [d for d in range(n_vis) if d != dev_index]
+            for d in others:
+                ctx.add_device(d)
+            once()
+            bm = 1e9
+            for _ in range(3):
+                t = time.perf_counter()
+                once()
+                bm = min(bm, time.perf_counter() - t)
+            okm = None
+            if not no_verify:
+                okm = bool(np.array_equal(oo_o, poo.array[: k + 1]) and np.array_equal(ids_o, pi.array[: int(oo_o[k])]))
+                if not okm:
+                    raise SystemExit("PARITY FAILURE: multi-device hutk_encode_batch ids differ from the oracle")
+            out["packed_pinned_all_devices"] = {
+                "value": round(n_bytes / bm / 1e9, 2), "unit": "GB/s", "ms": round(bm * 1e3, 2), "devices": n_vis,
+                "verified_vs_oracle": okm,
+                "note": "the same call on a context with hutk_ctx_add_device for every visible GPU: byte-balanced runs of "
+                        "whole documents, one host thread per device"}
+    except SystemExit:
+        raise
+    except Exception as e:  # (reported, never fatal for the line)
+        out["packed_pinned_all_devices"] = {"error": str(e)[:200]}
     for a in (pb, po, pi, poo):
         a.close()
     # the reference's own surface: list[str] -> list[list[int]]

@@ -44,9 +44,14 @@ def context():
 
 
 def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_encoder=False,
-                       special_token_id=-1, pattern=None, merges_file_path=None, device=-1):
+                       special_token_id=-1, pattern=None, merges_file_path=None, device=-1, devices=None):
     # mirrors the argument contract of _hutoken.initialize (lib.c:188-215, "ss|zpizz")
+    # devices (not in the reference): several GPUs of this process behind batch_encode (hutk_ctx_add_device)
     global _ctx
+    if devices is None and os.environ.get("HUTOKEN_DEVICES"):
+        devices = [int(x) for x in os.environ["HUTOKEN_DEVICES"].split(",") if x.strip()]
+    if devices:
+        device = int(devices[0])
     if not isinstance(vocab_file_path, str) or not isinstance(special_file_path, str) \
             or not (prefix is None or isinstance(prefix, str)) \
             or not (pattern is None or isinstance(pattern, str)) \
@@ -61,10 +66,12 @@ def _native_initialize(vocab_file_path, special_file_path, prefix=None, is_byte_
         old, _ctx = _ctx, _capi.Context.from_handle(sh.handle())
         if old is not None:
             old.close()
+        for d in (devices or [])[1:]:
+            _ctx.add_device(int(d))
         return None
     # merges_file_path: the id-keyed merge path (lib.c:573-663, core.c:211-337) on the same kernels
     new = _capi.Context(vocab_file_path, special_file_path, prefix, bool(is_byte_encoder), device,
-                        merges_path=merges_file_path)
+                        merges_path=merges_file_path, devices=devices)
     if pattern is not None:
         # the regex pre-token path (core.c:350-360): libc's regexec finds the words on the host, pretokenizer and
         # merge loop run on the GPU
@@ -104,7 +111,7 @@ def initialize(model_or_path, *args, **kwargs):
         if merges_kw and not os.path.isfile(merges_kw):
             raise ValueError(f"The provided merges file '{merges_kw}' does not exist.")
         return _native_initialize(model_or_path, special_chars_file, prefix, is_byte_encoder, token_id,
-                                  regex_pattern, merges_kw, device=device)
+                                  regex_pattern, merges_kw, device=device, devices=kwargs.get("devices", None))
     # Hugging Face branch (hutoken.py:44-120): convert the tokenizer to huToken's files, then the same native
     # initialisation, on the id-keyed merge path when the tokenizer has merge rules
     from . import hf

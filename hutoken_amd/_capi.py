@@ -17,11 +17,11 @@ DOC_OK, DOC_WORD_TOO_LARGE, DOC_INVALID_UTF8 = 0, 1, 2
 
 # every symbol include/hutoken_amd.h declares
 EXPORTS = [
-    "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_ctx_set_pattern", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
+    "hutk_ctx_create", "hutk_ctx_create_merges", "hutk_ctx_set_pattern", "hutk_ctx_add_device", "hutk_ctx_device_count", "hutk_uses_merges", "hutk_ctx_destroy", "hutk_last_error", "hutk_ids_capacity",
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
-    "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_tile_bytes",
+    "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_profile_raw", "hutk_debug_tile_bytes",
 ]
 
 _lib = None
@@ -71,8 +71,9 @@ def load(build_if_missing=True):
     L.hutk_ctx_create.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, i32]
     L.hutk_ctx_create_merges.restype = i32
     L.hutk_ctx_create_merges.argtypes = [C.POINTER(vp), C.c_char_p, C.c_char_p, C.c_char_p, i32, C.c_char_p, i32]
-    L.hutk_ctx_set_pattern.restype = i32
-    L.hutk_ctx_set_pattern.argtypes = [vp, C.c_char_p]
+    if hasattr(L, "hutk_ctx_set_pattern"):  # (older builds under tools/ab.py lack it)
+        L.hutk_ctx_set_pattern.restype = i32
+        L.hutk_ctx_set_pattern.argtypes = [vp, C.c_char_p]
     L.hutk_uses_merges.restype = i32
     L.hutk_uses_merges.argtypes = [vp]
     L.hutk_decode_batch.restype = i32
@@ -110,12 +111,20 @@ def load(build_if_missing=True):
     if hasattr(L, "hutk_debug_pairs_second"):  # (older builds under tools/ab.py lack it)
         L.hutk_debug_pairs_second.restype = i64
         L.hutk_debug_pairs_second.argtypes = [vp]
+    if hasattr(L, "hutk_ctx_add_device"):
+        L.hutk_ctx_add_device.restype = i32
+        L.hutk_ctx_add_device.argtypes = [vp, i32]
+        L.hutk_ctx_device_count.restype = i32
+        L.hutk_ctx_device_count.argtypes = [vp]
     L.hutk_debug_profile.restype = i32
     L.hutk_debug_profile.argtypes = [vp, i32]
     L.hutk_debug_tile_bytes.restype = i32
     L.hutk_debug_tile_bytes.argtypes = []
     L.hutk_debug_profile_read.restype = i32
     L.hutk_debug_profile_read.argtypes = [vp, i64, vp]
+    if hasattr(L, "hutk_debug_profile_raw"):
+        L.hutk_debug_profile_raw.restype = i32
+        L.hutk_debug_profile_raw.argtypes = [vp, i64, vp]
     _lib = L
     return L
 
@@ -188,8 +197,13 @@ class PinnedArray:
 class Context:
     """Owns one hutk_ctx."""
 
-    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, device=-1, merges_path=None):
+    def __init__(self, vocab_path, special_path, prefix=None, is_byte_encoder=False, device=-1, merges_path=None,
+                 devices=None):
+        """devices: several ordinals of this process; encode_packed() / hutk_encode_batch then spreads a large batch
+        over them (hutk_ctx_add_device).  The first one is the context's own device."""
         L = load()
+        if devices:
+            device = int(devices[0])
         h = C.c_void_p()
         rc = L.hutk_ctx_create_merges(C.byref(h), os.fsencode(vocab_path), os.fsencode(special_path),
                                       None if prefix is None else prefix.encode("utf-8"),
@@ -198,6 +212,19 @@ class Context:
         raise_for(rc)
         self._h = h
         self._owned = True
+        for d in (devices or [])[1:]:
+            try:
+                self.add_device(int(d))
+            except Exception:
+                self.close()
+                raise
+
+    def add_device(self, device):
+        raise_for(load().hutk_ctx_add_device(self._h, device))
+
+    @property
+    def device_count(self):
+        return load().hutk_ctx_device_count(self._h)
 
     @classmethod
     def from_handle(cls, address):
@@ -316,6 +343,12 @@ class Context:
         out = np.zeros(10, dtype=np.float64)
         raise_for(load().hutk_debug_profile_read(self._h, n_tiles, out.ctypes.data))
         return out.tolist()
+
+    def profile_raw(self, n_tiles):
+        import numpy as np
+        out = np.zeros((n_tiles, 10), dtype=np.int64)
+        raise_for(load().hutk_debug_profile_raw(self._h, n_tiles, out.ctypes.data))
+        return out
 
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -135,6 +135,14 @@ struct hutk_ctx {
     std::recursive_mutex mu;
     hipEvent_t ev_busy = nullptr;
     bool busy_valid = false;
+
+    // Single-process multi-device dispatch (hutk_ctx_add_device): further contexts with the same tables on other
+    // devices; hutk_encode_batch cuts a large batch into byte-balanced runs of whole documents, one per device, and
+    // every run is encoded by its device's context on a host thread of its own.  peer_ids: page-locked landing area
+    // of a peer's ids (they are copied to their place once the runs before them are counted).
+    std::vector<hutk_ctx*> peers;
+    struct PeerBuf { int32_t* p = nullptr; size_t cap = 0; };
+    std::vector<PeerBuf> peer_ids;
 };
 
 namespace {
@@ -339,6 +347,11 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
 
 void destroy(hutk_ctx* c) {
     if (!c) return;
+    for (hutk_ctx* p : c->peers) destroy(p);
+    c->peers.clear();
+    for (auto& b : c->peer_ids)
+        if (b.p) (void)hipHostFree(b.p);
+    c->peer_ids.clear();
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
@@ -426,6 +439,30 @@ int build_word_table(hutk_ctx* c) {
     return HUTK_OK;
 }
 
+// The device half of a context whose host tables are loaded: stream, events, tables and whole-word table on `device`
+// (-1: the calling thread's current device).
+int attach_device(hutk_ctx* c, int device) {
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return set_err(HUTK_E_DEVICE, "no HIP device available: the hutoken_amd encode path runs on the GPU only");
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n_dev) return set_err(HUTK_E_ARG, "device ordinal out of range");
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) return set_err(HUTK_E_DEVICE, "hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return set_err(HUTK_E_DEVICE, "hipStreamCreate failed");
+    bool ok = true;
+    for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_busy, hipEventDisableTiming) == hipSuccess;
+    if (!ok) return set_err(HUTK_E_DEVICE, "hipEventCreate failed");
+    int rc = upload_tables(c);
+    if (rc == HUTK_OK && !getenv("HUTK_NO_WORD_TABLE")) rc = build_word_table(c);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -457,35 +494,7 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
         *out = c;
         return HUTK_OK;
     }
-    int n_dev = 0;
-    hipError_t e = hipGetDeviceCount(&n_dev);
-    if (e != hipSuccess || n_dev <= 0) {
-        delete c;
-        return set_err(HUTK_E_DEVICE,
-                       "no HIP device available: the hutoken_amd encode path runs on the GPU only");
-    }
-    if (device < 0) {
-        if (hipGetDevice(&device) != hipSuccess) device = 0;
-    }
-    if (device >= n_dev) {
-        delete c;
-        return set_err(HUTK_E_ARG, "device ordinal out of range");
-    }
-    c->device = device;
-    int rc = HUTK_OK;
-    do {
-        if (hipSetDevice(device) != hipSuccess) { rc = set_err(HUTK_E_DEVICE, "hipSetDevice failed"); break; }
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-            rc = set_err(HUTK_E_DEVICE, "hipStreamCreate failed");
-            break;
-        }
-        bool ok = true;
-        for (auto& ev : c->ev) ok = ok && hipEventCreate(&ev) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&c->ev_busy, hipEventDisableTiming) == hipSuccess;
-        if (!ok) { rc = set_err(HUTK_E_DEVICE, "hipEventCreate failed"); break; }
-        rc = upload_tables(c);
-        if (rc == HUTK_OK && !getenv("HUTK_NO_WORD_TABLE")) rc = build_word_table(c);
-    } while (0);
+    const int rc = attach_device(c, device);
     if (rc) {
         std::string keep = g_err;
         destroy(c);
@@ -495,6 +504,30 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
     *out = c;
     return HUTK_OK;
 }
+
+int hutk_ctx_add_device(hutk_ctx* c, int device) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
+    if (device < 0) return set_err(HUTK_E_ARG, "device ordinal out of range");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    hutk_ctx* p = new (std::nothrow) hutk_ctx();
+    if (!p) return set_err(HUTK_E_MEMORY, "out of memory");
+    p->tab = c->tab;  // the host tables as loaded: same files, same ids
+    p->pattern = c->pattern;
+    p->timing = false;
+    const int rc = attach_device(p, device);
+    if (rc) {
+        std::string keep = g_err;
+        destroy(p);
+        g_err = keep;
+        return rc;
+    }
+    c->peers.push_back(p);
+    c->peer_ids.emplace_back();
+    return HUTK_OK;
+}
+
+int hutk_ctx_device_count(const hutk_ctx* c) { return c && !c->host_only ? 1 + (int)c->peers.size() : 0; }
 
 void hutk_ctx_destroy(hutk_ctx* ctx) { destroy(ctx); }
 
@@ -544,6 +577,14 @@ int hutk_debug_profile_read(hutk_ctx* c, int64_t n_tiles, double* out10) {
         for (int k = 1; k < 10; k++) out10[k] += (double)(h[t * 10 + k] - h[t * 10 + k - 1]);
     for (int k = 1; k < 10; k++) out10[k] /= (double)n_tiles;
     for (int k = 1; k < 10; k++) out10[0] += out10[k];
+    return HUTK_OK;
+}
+
+// the stamps themselves, ten per tile
+int hutk_debug_profile_raw(hutk_ctx* c, int64_t n_tiles, long long* out) {
+    if (!c || !out || !c->w_prof.p || n_tiles <= 0) return set_err(HUTK_E_ARG, "no profile");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, c->w_prof.p, (size_t)n_tiles * 10 * 8, hipMemcpyDeviceToHost));
     return HUTK_OK;
 }
 
@@ -730,6 +771,7 @@ int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (!pattern) {
         c->pattern.clear();
+        for (hutk_ctx* p : c->peers) p->pattern.clear();
         return HUTK_OK;
     }
     if (c->tab.has_prefix)
@@ -739,12 +781,13 @@ int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
         return set_err(HUTK_E_VALUE, "Regex could not be compiled.");  // core.c:352-358
     regfree(&re);
     c->pattern = pattern;
+    for (hutk_ctx* p : c->peers) p->pattern = pattern;
     return HUTK_OK;
 }
 
-int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
-                      int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
-    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+// one context, one device
+static int encode_batch_one(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                            int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
     std::lock_guard<std::recursive_mutex> lock(c->mu);  // (the staging buffers are the context's too)
     if (c && !c->host_only && !c->pattern.empty())
         return encode_batch_regex(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
@@ -755,6 +798,110 @@ int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets,
         if (!redo) return rc;
     }
     return encode_batch_simple(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
+}
+
+// Several devices in one process (SURVEY section 8(b) `device_mask`; the reference's batch_encode spreads documents over
+// host threads with a DP on their lengths, lib.c:779-794): runs of whole documents with about the same number of BYTES,
+// one per device, encoded side by side; run k's ids land in page-locked memory of their own and are copied behind
+// those of runs 0..k-1 once these are counted (run 0 writes in place).  Same ids, offsets and status as on one device.
+static int64_t multi_min_bytes() {
+    const char* e = getenv("HUTK_MULTI_MIN_BYTES");
+    return e ? atoll(e) : (4ll << 20);  // below this a second device's copies cost more than they save
+}
+
+static int encode_batch_multi(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                              int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    const int n_dev = 1 + (int)c->peers.size();
+    const int64_t n_bytes = offsets[n_docs];
+    const int64_t need = hutk_ids_capacity(c, n_bytes, n_docs) - 1;
+    if (ids_cap < need) return set_err(HUTK_E_CAPACITY, "ids_cap is below hutk_ids_capacity()");
+    // cut k: the first document that starts at or after k/n of the bytes
+    std::vector<int64_t> lo((size_t)n_dev + 1, n_docs);
+    lo[0] = 0;
+    for (int k = 1; k < n_dev; k++) {
+        const int64_t target = n_bytes / n_dev * k;
+        lo[k] = std::lower_bound(offsets, offsets + n_docs + 1, target) - offsets;
+        if (lo[k] > n_docs) lo[k] = n_docs;
+        if (lo[k] < lo[k - 1]) lo[k] = lo[k - 1];
+    }
+    struct Run {
+        std::vector<int64_t> offs, oo;
+        int32_t* ids = nullptr;
+        int64_t cap = 0;
+        int rc = HUTK_OK;
+        std::string msg;
+    };
+    std::vector<Run> runs((size_t)n_dev);
+    for (int k = 0; k < n_dev; k++) {
+        Run& r = runs[(size_t)k];
+        const int64_t a = lo[k], b = lo[k + 1], nd = b - a;
+        r.offs.resize((size_t)nd + 1);
+        for (int64_t i = 0; i <= nd; i++) r.offs[(size_t)i] = offsets[a + i] - offsets[a];
+        r.oo.assign((size_t)nd + 1, 0);
+        hutk_ctx* ck = k ? c->peers[(size_t)k - 1] : c;
+        r.cap = hutk_ids_capacity(ck, r.offs[(size_t)nd], nd) - 1;
+        if (k == 0) {
+            r.ids = ids_out;
+        } else {
+            hutk_ctx::PeerBuf& pb = c->peer_ids[(size_t)k - 1];
+            if (pb.cap < (size_t)r.cap + 1) {
+                if (pb.p) (void)hipHostFree(pb.p);
+                pb.p = nullptr;
+                pb.cap = 0;
+                const size_t want = (size_t)r.cap + (size_t)r.cap / 8 + 64;
+                HIP_TRY(hipSetDevice(ck->device));
+                HIP_TRY(hipHostMalloc((void**)&pb.p, want * 4, hipHostMallocPortable));
+                pb.cap = want;
+            }
+            r.ids = pb.p;
+        }
+    }
+    auto encode_run = [&](int k) {
+        Run& r = runs[(size_t)k];
+        hutk_ctx* ck = k ? c->peers[(size_t)k - 1] : c;
+        const int64_t a = lo[k], nd = lo[k + 1] - a;
+        r.rc = encode_batch_one(ck, bytes + offsets[a], r.offs.data(), nd, r.ids, r.cap, r.oo.data(),
+                                status ? status + a : nullptr);
+        if (r.rc) r.msg = g_err;  // (the message is the thread's)
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_dev; k++) th.emplace_back(encode_run, k);
+        encode_run(0);
+        for (auto& t : th) t.join();
+    }
+    for (int k = 0; k < n_dev; k++)
+        if (runs[(size_t)k].rc) return set_err(runs[(size_t)k].rc, runs[(size_t)k].msg);
+    std::vector<int64_t> base((size_t)n_dev + 1, 0);
+    for (int k = 0; k < n_dev; k++) base[(size_t)k + 1] = base[(size_t)k] + runs[(size_t)k].oo.back();
+    if (base[(size_t)n_dev] > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
+    auto place_run = [&](int k) {
+        const Run& r = runs[(size_t)k];
+        const int64_t a = lo[k], nd = lo[k + 1] - a, b0 = base[(size_t)k];
+        if (k && r.oo.back()) memcpy(ids_out + b0, r.ids, (size_t)r.oo.back() * 4);
+        for (int64_t i = 0; i < nd; i++) out_offsets[a + i] = b0 + r.oo[(size_t)i];
+    };
+    {
+        std::vector<std::thread> th;
+        for (int k = 1; k < n_dev; k++) th.emplace_back(place_run, k);
+        place_run(0);
+        for (auto& t : th) t.join();
+    }
+    out_offsets[n_docs] = base[(size_t)n_dev];
+    return HUTK_OK;
+}
+
+int hutk_encode_batch(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                      int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!c->peers.empty() && offsets && out_offsets && bytes && ids_out && n_docs >= 1 + (int64_t)c->peers.size() &&
+        offsets[0] == 0 && offsets[n_docs] >= multi_min_bytes()) {
+        bool sane = true;
+        for (int64_t i = 0; i < n_docs && sane; i++) sane = offsets[i + 1] >= offsets[i];
+        if (sane) return encode_batch_multi(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
+    }
+    return encode_batch_one(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
 }
 
 int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d_id_offsets, int64_t n_docs,

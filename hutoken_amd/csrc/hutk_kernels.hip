@@ -284,10 +284,20 @@ constexpr int TILE_WAVES = HUTK_TILE_WAVES;  // tiles (= wavefronts) per workgro
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
 
-#define HUTK_STAMP(k)                                                          \
+#ifndef HUTK_MERGE_STAMPS
+#define HUTK_MERGE_STAMPS 0  // 1: MEASUREMENT ONLY, the ten clock stamps are spent inside the merge phase (tools/profile_phases.py)
+#endif
+#define HUTK_STAMP_AT(k)                                                       \
     do {                                                                       \
         if (W.prof && lane == 0) W.prof[tile * N_PHASE + (k)] = clock64();     \
     } while (0)
+#if HUTK_MERGE_STAMPS
+#define HUTK_STAMP(k) do {} while (0)
+#define HUTK_MSTAMP(k) do { if (tile_ok) HUTK_STAMP_AT(k); } while (0)
+#else
+#define HUTK_STAMP(k) HUTK_STAMP_AT(k)
+#define HUTK_MSTAMP(k) do {} while (0)
+#endif
 
 // byte k (0..31) of a 32-byte register window
 struct Win { uint64_t a, b, c, d; };
@@ -709,10 +719,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_ABLATE_MERGE
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
 #endif
+    [[maybe_unused]] bool first_epoch = true;
     if constexpr (KEEP > 1)
     for (;;) {
+        if (first_epoch) HUTK_MSTAMP(0);
         if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
         __syncthreads();
+        if (first_epoch) HUTK_MSTAMP(1);
         uint32_t pending = 0;
         if (tile_ok) {
             pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
@@ -737,7 +750,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
             reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)(pending | later);
         }
+        if (first_epoch) HUTK_MSTAMP(2);
         __syncthreads();
+        if (first_epoch) { HUTK_MSTAMP(3); HUTK_MSTAMP(4); }
         const uint32_t n_long = min(pool_cnt[0], (uint32_t)POOL_LONG_CAP);
         const uint32_t n_pool = n_long + min(pool_cnt[1], (uint32_t)(POOL_CAP - POOL_LONG_CAP));
         for (uint32_t base = 64u * wv; base < n_pool; base += 64u * WAVES) {
@@ -817,6 +832,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     cand &= (1u << (n - 1)) - 1u;  // the last unit has no next one (n >= 2)
                     best = scan_key(cand);
                 }
+                if (first_epoch && base == 64u * wv) HUTK_MSTAMP(4);
                 // One merge per trip: apply the best pair, ISSUE the lookups of the two new neighbour pairs, rescan the
                 // untouched candidates while those loads fly, then fold the two new keys in.
                 for (;;) {
@@ -981,8 +997,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 wave_sync();
             }
         }
-        if (!__syncthreads_or(pending != 0)) break;
+        if (first_epoch) HUTK_MSTAMP(5);
+        const bool again = __syncthreads_or(pending != 0);
+        if (first_epoch) HUTK_MSTAMP(6);
+        first_epoch = false;
+        if (!again) break;
     }
+    HUTK_MSTAMP(7);
+    HUTK_MSTAMP(8);
+    HUTK_MSTAMP(9);
     if (tile_ok) HUTK_STAMP(5);
 
     if (!tile_ok) return;

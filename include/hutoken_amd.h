@@ -88,6 +88,17 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
  * code); HUTK_E_UNSUPPORTED: the context has a prefix.  hutk_encode_batch_device refuses a context with a pattern. */
 int hutk_ctx_set_pattern(hutk_ctx* ctx, const char* pattern);
 
+/* Several GPUs behind ONE context of one process (`device_mask`).  The reference's
+ * batch_encode spreads the documents of a batch over host threads, balanced by a DP on their lengths
+ * (src/lib.c:779-794, 48-57); here hutk_encode_batch cuts a batch of at least 4 MiB (HUTK_MULTI_MIN_BYTES overrides) into
+ * runs of whole documents with about the same number of bytes, one per device, encodes them side by side on a host
+ * thread each, and puts the ids together in document order: ids, offsets and status are those of one device.
+ * hutk_ctx_add_device adds `device` (an ordinal of this process; the same ordinal may be added again) with the tables
+ * the context was created from; everything that takes device pointers (hutk_encode_batch_device,
+ * hutk_decode_batch_device) and the decode direction stay on the context's first device. */
+int hutk_ctx_add_device(hutk_ctx* ctx, int device);
+int hutk_ctx_device_count(const hutk_ctx* ctx); /* 1 + the devices added; 0 for a host-only context */
+
 /* The reference never frees its contexts (lib.c:129-155); this one can be. */
 void hutk_ctx_destroy(hutk_ctx* ctx);
 
@@ -193,6 +204,7 @@ int64_t hutk_debug_pairs_second(const hutk_ctx* ctx);
 int hutk_debug_profile(hutk_ctx* ctx, int enable);
 int hutk_debug_tile_bytes(void); /* input bytes per tile of the hot kernel */
 int hutk_debug_profile_read(hutk_ctx* ctx, int64_t n_tiles, double* out10);
+int hutk_debug_profile_raw(hutk_ctx* ctx, int64_t n_tiles, long long* out); /* the stamps, ten per tile */
 
 /* Per-call profiling events cost a little; they are on by default. */
 void hutk_set_timing(hutk_ctx* ctx, int enabled);

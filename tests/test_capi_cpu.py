@@ -37,6 +37,11 @@ def test_no_gpu_means_loud_failure(tmp_path):
     import numpy as np
     with pytest.raises(RuntimeError, match="host-only"):
         host.encode_packed(np.frombuffer(b"abc", dtype=np.uint8), np.array([0, 3], dtype=np.int64))
+    with pytest.raises(RuntimeError, match="host-only"):  # no device to add a second one to
+        host.add_device(0)
+    assert host.device_count == 0
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _capi.Context(vp, spath, None, True, devices=[0, 1])
 
 
 def test_product_never_imports_the_oracle():

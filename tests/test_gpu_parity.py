@@ -375,3 +375,46 @@ def test_two_streams_and_two_threads_on_one_context(vg_files, oracle_mod):
     for k in range(2):
         ids, oo, st, rc = results[k]
         assert rc == 0 and np.array_equal(oo, batches[k][7][1]) and np.array_equal(ids, batches[k][7][0])
+
+
+@pytest.mark.parametrize("n_dev", [2, 3])
+def test_one_batch_over_several_device_contexts(vg_files, oracle_mod, monkeypatch, n_dev):
+    """hutk_ctx_add_device: the batch is cut into byte-balanced runs of whole documents, one per device context, encoded
+    side by side and put together in document order.  The box has one GPU, so the same ordinal is added again: every
+    step of the dispatch runs (cuts, threads, per-device tables and staging, placement), only the speed-up does not."""
+    from hutoken_amd import _capi, synth
+    vp, sp, kw = vg_files
+    monkeypatch.setenv("HUTK_MULTI_MIN_BYTES", "0")
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], devices=[0] * n_dev)
+    assert ctx.device_count == n_dev
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C3", 5000, first_doc=123_000)
+    # ragged: empty documents at the front, in the middle and at the end, and one document of a third of the bytes
+    cuts = o.tolist()
+    big = len(d) // 3
+    keep = [c for c in cuts if not (cuts[700] < c < cuts[700] + big)]
+    o2 = np.array([0, 0] + keep[1:1000] + [keep[1000]] * 3 + keep[1001:] + [keep[-1]] * 2, dtype=np.int64)
+    for dd, oo_in in ((d, o), (d, o2)):
+        want_ids, want_oo, want_st = orc.encode_packed(dd, oo_in, 8)
+        ids, oo, st, rc = ctx.encode_packed(dd, oo_in)
+        assert rc == 0
+        assert np.array_equal(oo, want_oo) and np.array_equal(ids, want_ids) and np.array_equal(st, want_st)
+    # fewer documents than devices, and an empty batch: the context's own device takes them
+    d1, o1 = synth.corpus("C3", 1)
+    ids, oo, st, rc = ctx.encode_packed(d1, o1)
+    assert rc == 0 and np.array_equal(ids, orc.encode_packed(d1, o1, 1)[0])
+    # an error in one run is the call's error (a NUL byte in the last third)
+    bad = d.copy()
+    bad[len(bad) - 1000] = 0
+    with pytest.raises(Exception):
+        r = ctx.encode_packed(bad, o)
+        if r[3] != 0:
+            raise RuntimeError("rc %d" % r[3])
+    # the regex pre-token path goes through the same dispatch
+    ctx.set_pattern(r"[A-Za-z]+|[0-9]+|[^A-Za-z0-9 ]+| +")
+    orx = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], pattern=r"[A-Za-z]+|[0-9]+|[^A-Za-z0-9 ]+| +")
+    d3, o3 = synth.corpus("C2", 800)
+    want_ids, want_oo, _ = orx.encode_packed(d3, o3, 8)
+    ids, oo, st, rc = ctx.encode_packed(d3, o3)
+    assert rc == 0 and np.array_equal(oo, want_oo) and np.array_equal(ids, want_ids)
+    ctx.close()

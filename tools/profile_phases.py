@@ -36,4 +36,13 @@ ph = ctx.profile_read(n_tiles)
 names = ["total", "1 stage+docs", "2 classify", "3 byte pairs", "4 bucket words", "5 merge", "6 scan+meta", "7 write ids", "8 docpos", "9 -"]
 for nme, v in zip(names, ph):
     print(f"  {nme:18s} {v:10.0f} cyc  {100*v/ph[0]:5.1f}%")
+if os.environ.get("HUTK_MERGE_STAMPS_BUILD"):
+    # a -DHUTK_MERGE_STAMPS=1 build: the stamps are inside the merge phase; per wavefront of the workgroup
+    raw = ctx.profile_raw(n_tiles)[: n_tiles // 4 * 4].reshape(-1, 4, 10)
+    names = ["barrier 1 (wait)", "pool fill", "barrier 2 (wait)", "set-up", "trips", "barrier 3 (wait)", "tail"]
+    for wv in range(4):
+        dlt = np.diff(raw[:, wv, :8], axis=1).mean(axis=0)
+        print(f"  wavefront {wv}: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, dlt)))
+    span = (raw[:, :, 7].max(axis=1) - raw[:, :, 0].min(axis=1)).mean()
+    print(f"  workgroup: first arrival to last exit {span:.0f} cycles")
 ctx.profile(False)
