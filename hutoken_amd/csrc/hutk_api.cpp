@@ -403,12 +403,14 @@ int build_word_table(hutk_ctx* c) {
                                oo.data(), nullptr);
     c->dt.has_prefix = had_prefix;
     if (rc) return rc;
+    const int64_t key_bytes = T.sym16 ? WORD_KEY_BYTES_16 : WORD_KEY_BYTES_32;  // (WordSlot, hutk_device.h)
     std::vector<size_t> keep;
     for (size_t i = 0; i < n; i++)
-        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
+        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2 &&
+            offs[i + 1] - offs[i] <= key_bytes)
             keep.push_back(i);
     if (keep.empty()) return HUTK_OK;
-    // two-choice cuckoo table of 20-byte slots (hutk_device.h); a word that cannot be placed is simply left out
+    // two-choice cuckoo table of 16-byte slots (hutk_device.h); a word that cannot be placed is simply left out
     std::vector<uint4> kk(keep.size());
     for (size_t q = 0; q < keep.size(); q++) {
         const size_t i = keep[q];
@@ -423,12 +425,13 @@ int build_word_table(hutk_ctx* c) {
     auto hash_of = [&](uint32_t j) { const uint4 k = kk[j]; return word_hash(k.x, k.y, k.z, k.w); };
     cuckoo_place(keep.size(), cap, [&](uint32_t j) { return hash_of(j) & (cap - 1); },
                  [&](uint32_t j) { return word_slot2(hash_of(j), cap - 1); }, where, &homeless);
-    std::vector<WordSlot> slots(cap + 1, WordSlot{{0, 0, 0, 0}, 0});
+    std::vector<WordSlot> slots(cap + 1, WordSlot{{0, 0, 0, 0}});
     size_t placed = 0;
     for (size_t j = 0; j < keep.size(); j++) {
         if (where[j] == 0xFFFFFFFFu) continue;
         const uint4 k = kk[j];
-        slots[where[j]] = WordSlot{{k.x, k.y, k.z, k.w}, T.cand_sym[keep[j]]};
+        slots[where[j]] = T.sym16 ? WordSlot{{k.x, k.y, k.z, k.w | (T.cand_sym[keep[j]] << 16)}}
+                                  : WordSlot{{k.x, k.y, k.z, T.cand_sym[keep[j]]}};
         placed++;
     }
     HIP_TRY(c->d_word_tab.reserve(slots.size()));

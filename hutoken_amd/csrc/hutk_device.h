@@ -33,8 +33,12 @@ constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units me
 // function of a +-3 byte neighbourhood)
 enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE = 4, C_WS = 5, C_BAD = 6 };
 
-// slot of the whole-word table: 16 key bytes as four little-endian dwords, then the symbol (20 bytes, dword aligned)
-struct WordSlot { uint32_t k[4]; uint32_t sym; };
+// Slot of the whole-word table: ONE 16-byte load.  Key bytes as little-endian dwords, zero padded, and the symbol in
+// what the key leaves free: 16-bit symbols (vocabularies below 65520 symbols): 14 key bytes, symbol in the top half of
+// k[3]; otherwise 12 key bytes, symbol = k[3].  (Round 2 began with 20-byte slots for 16-byte keys: two L1 accesses per
+// slot, and the kernel is bound by the number of gather accesses)
+struct WordSlot { uint32_t k[4]; };
+constexpr int WORD_KEY_BYTES_16 = 14, WORD_KEY_BYTES_32 = 12;
 
 struct DevTables {
     const uint4* pair_buckets;  // two entries per bucket {w0, w1, w0, w1}, see hutk_internal.h
@@ -59,8 +63,8 @@ struct DevTables {
     // only).  Slower on the benchmark's text (two kernels bound by table gathers one after the other, 146 against 175
     // GB/s), faster where every word merges (81 against 68 GB/s on 17-31-letter random words): off unless asked for
     int32_t split_merge;
-    // whole-word table: raw word bytes of 2..16 bytes (zero padded to 16) -> symbol of the one token the word encodes to.
-    // Two-choice cuckoo, 20-byte slots, an empty slot is all zero (a key's first bytes never are); slot 1 = hash & mask,
+    // whole-word table: raw word bytes of 2..14 (12) bytes, zero padded -> symbol of the one token the word encodes to.
+    // Two-choice cuckoo, 16-byte slots (WordSlot), an empty slot is all zero (a key's first bytes never are); slot 1 = hash & mask,
     // slot 2 = word_slot2(hash, mask) (hutk_internal.h).  word_mask == 0: no table.
     const WordSlot* word_tab;
     uint32_t word_mask;

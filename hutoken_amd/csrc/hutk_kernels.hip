@@ -108,6 +108,12 @@ __device__ __noinline__ uint32_t classify16_exact_cold(Win8 w, uint32_t dbits) {
 // One wavefront per workgroup: LDS instructions of a wavefront execute in order, so lanes exchange data
 // through LDS without s_barrier -- and without the "wait for every outstanding global load and STORE"
 // that __syncthreads() implies.  This only stops the compiler from moving LDS accesses across the point.
+// index of the lowest set bit; -1 (all ones) for 0 -- the hardware's own answer, which the merge loop's scan relies on
+__device__ __forceinline__ int ffbl_raw(uint32_t x) {
+    int r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -269,6 +275,11 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //   HUTK_FAST_MERGE   0: the general merge loop also where the short form (packed keys) applies
 //   HUTK_STAGE_RUN    1: a tile's symbols go to HBM through LDS as 16-byte stores instead of lane by lane (measured: -1 %)
 //   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
+//   HUTK_SCAN_RAW     1: the rescan takes "no candidate left" as index -1 (v_ffbl's answer for 0), whose key is all ones:
+//                     25 instead of 37 VALU instructions per four candidates; measured -0.4 % alone
+//   HUTK_PUBLISH_LATE 1: a word's surviving units are published after the trip loop instead of in the trip it ends in;
+//                     measured +0.4 % alone, -3 % together with HUTK_SCAN_RAW
+//   HUTK_MERGE_STAMPS 1: MEASUREMENT ONLY, the clock stamps are spent inside the merge phase
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
 #ifndef HUTK_CHAR_EU
@@ -284,6 +295,24 @@ constexpr int TILE_WAVES = HUTK_TILE_WAVES;  // tiles (= wavefronts) per workgro
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
 
+#ifndef HUTK_PERTURB_VALU
+#define HUTK_PERTURB_VALU 0
+#endif
+#ifndef HUTK_PERTURB_MEM
+#define HUTK_PERTURB_MEM 0
+#endif
+#ifndef HUTK_PERTURB_SLEEP
+#define HUTK_PERTURB_SLEEP 0
+#endif
+#ifndef HUTK_LANE_RETRY
+#define HUTK_LANE_RETRY 1
+#endif
+#ifndef HUTK_SCAN_RAW
+#define HUTK_SCAN_RAW 0
+#endif
+#ifndef HUTK_PUBLISH_LATE
+#define HUTK_PUBLISH_LATE 0
+#endif
 #ifndef HUTK_MERGE_STAMPS
 #define HUTK_MERGE_STAMPS 0  // 1: MEASUREMENT ONLY, the ten clock stamps are spent inside the merge phase (tools/profile_phases.py)
 #endif
@@ -547,6 +576,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
         }
         wmask16[lane] = (uint16_t)flags;
+#if HUTK_PERTURB_VALU
+        {   // MEASUREMENT ONLY: extra VALU instructions (a dependent chain, every lane) -- is the kernel bound by VALU issue?
+            uint32_t x = flags | 1u;
+            for (int i = 0; i < HUTK_PERTURB_VALU / 4; i++) {
+                x ^= x << 13; x ^= x >> 17;
+                asm volatile("" : "+v"(x));
+            }
+            if (x == 0x9E3779B9u) raise(A.err, HUTK_E_MEMORY);
+        }
+#endif
         HUTK_STAMP(2);
 
         wave_sync();
@@ -603,8 +642,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 //   byte mode: symbol of the first byte (all a one-byte word needs)
                 //   whole-word table: the word's raw bytes (zero padded to 16) -> symbol of the single token it
                 //   encodes to; two-choice cuckoo tables, entries verified by this pipeline at context creation;
-                //   one table for words of 2..16 bytes, 20-byte slots {16 key bytes, symbol}
-                const bool probe = !gap && !exc && !pfx && T.word_mask && nb >= 2 && nb <= 16;
+                //   one table for words of 2..14 bytes (12 with 32-bit symbols), 16-byte slots {key bytes, symbol}: one load each
+                constexpr int WORD_KEY = sizeof(SymT) == 2 ? WORD_KEY_BYTES_16 : WORD_KEY_BYTES_32;
+                const bool probe = !gap && !exc && !pfx && T.word_mask && nb >= 2 && nb <= WORD_KEY;
                 uint32_t k0, k1, k2, k3;
                 {
                     const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
@@ -625,20 +665,35 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const uint32_t wh = word_hash(k0, k1, k2, k3);
                 const uint32_t h1 = probe ? wh & T.word_mask : 0u;
                 const uint32_t h2 = probe ? word_slot2(wh, T.word_mask) : 0u;
-                WordSlot s1{}, s2{};
+                uint4 s1 = make_uint4(0, 0, 0, 0), s2 = s1;
                 uint32_t isym = 0;
                 if (T.word_mask) {  // uniform
-                    s1 = T.word_tab[h1];
-                    s2 = T.word_tab[h2];
+                    s1 = reinterpret_cast<const uint4*>(T.word_tab)[h1];
+                    s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
                 }
                 if (BYTE_MODE) isym = T.item_sym[b0];
+#if HUTK_PERTURB_MEM
+                {   // MEASUREMENT ONLY: extra 16-byte gathers per word -- is the kernel bound by the L1 / L2 request rate?
+                    uint32_t acc = 0;
+#pragma unroll
+                    for (int j = 0; j < HUTK_PERTURB_MEM; j++) {
+                        const uint4 v = T.pair_buckets[(wh * (2u * j + 3u) * 0x9E3779B1u) >> T.pair_shift];
+                        acc ^= v.x ^ v.w;
+                    }
+                    if (acc == 0x12345678u && wh == 0x9E3779B9u) raise(A.err, HUTK_E_MEMORY);
+                }
+#endif
                 bool done = false;
                 if (probe) {
                     // bitwise on purpose: with && the compiler fetches one word first and the rest only on a match
-                    const bool hit1 = ((s1.k[0] ^ k0) | (s1.k[1] ^ k1) | (s1.k[2] ^ k2) | (s1.k[3] ^ k3)) == 0;
-                    const bool hit2 = ((s2.k[0] ^ k0) | (s2.k[1] ^ k1) | (s2.k[2] ^ k2) | (s2.k[3] ^ k3)) == 0;
+                    // (the probed word's bytes beyond WORD_KEY are zero: k3 has nothing in the symbol's place)
+                    constexpr int KSH = sizeof(SymT) == 2 ? 16 : 32;  // bits of k[3] that are symbol, not key
+                    const uint32_t d1 = KSH == 32 ? 0u : (s1.w ^ k3) << (KSH & 31), d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
+                    const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2) | d1) == 0;
+                    const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2) | d2) == 0;
                     done = hit1 || hit2;
-                    if (done) S[ws] = Sym<SymT>::narrow(hit1 ? s1.sym : s2.sym);
+                    const uint32_t sw = hit1 ? s1.w : s2.w;
+                    if (done) S[ws] = Sym<SymT>::narrow(KSH == 32 ? sw : sw >> (KSH & 31));
                 }
                 int n = 0;
                 SymT* Sdst = S + ws;
@@ -719,11 +774,17 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_ABLATE_MERGE
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
 #endif
+#if HUTK_PERTURB_SLEEP
+    for (int i = 0; i < HUTK_PERTURB_SLEEP; i++) __builtin_amdgcn_s_sleep(127);  // MEASUREMENT ONLY: ~8 k cycles each, no VALU
+#endif
     [[maybe_unused]] bool first_epoch = true;
     if constexpr (KEEP > 1)
     for (;;) {
-        if (first_epoch) HUTK_MSTAMP(0);
-        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = 0; }
+#if HUTK_MERGE_STAMPS
+        if (first_epoch && tile_ok && W.prof && lane == 0)  // the SIMD this wavefront runs on (HW_ID bits 5:4) in the stamp's low bits
+            W.prof[tile * N_PHASE + 0] = (clock64() & ~3ll) | (long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+#endif
+        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = (FAST && HUTK_SCAN_RAW) ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
         __syncthreads();
         if (first_epoch) HUTK_MSTAMP(1);
         uint32_t pending = 0;
@@ -784,10 +845,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 auto scan_key = [&](uint32_t c) -> uint32_t {  // four candidates per step, their LDS reads in flight together
                     uint32_t b = NOKEY;
                     while (c) {
+                        // fewer than four left: the index of "no bit" is -1, whose key is all ones whatever m[offset - 1]
+                        // holds (a word's stretch never starts at m[0], so that is a slot of this array)
                         const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
+#if HUTK_SCAN_RAW
+                        const int i0 = ffbl_raw(c), i1 = ffbl_raw(c1), i2 = ffbl_raw(c2), i3 = ffbl_raw(c3);
+#else
                         const int i0 = __builtin_ctz(c);
                         const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
                                   i3 = c3 ? __builtin_ctz(c3) : i0;
+#endif
                         const uint32_t k0 = ((uint32_t)Mw[i0] << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw[i1] << 5) | (uint32_t)i1,
                                        k2 = ((uint32_t)Mw[i2] << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw[i3] << 5) | (uint32_t)i3;
                         b = min(min(b, k0), min(min(k1, k2), k3));
@@ -835,13 +902,127 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 if (first_epoch && base == 64u * wv) HUTK_MSTAMP(4);
                 // One merge per trip: apply the best pair, ISSUE the lookups of the two new neighbour pairs, rescan the
                 // untouched candidates while those loads fly, then fold the two new keys in.
+                const bool mine = have;
+#if HUTK_MERGE_STAMPS
+                long long ts_issue = 0, ts_scan = 0, ts_resolve = 0, ts_trips = 0;
+#endif
+#if HUTK_LANE_RETRY
+                // A lookup that must go on in the pair's SECOND bucket (a filter bit of the first one says so; under 1 % of
+                // the lookups) is not followed up inside the trip: with 64 lanes and two lookups each, nearly every trip
+                // had some lane in that case, and every lane paid its extra round trip(s).  The lane keeps its trip's state
+                // in two registers instead and REPEATS both lookups in the next trip, from the buckets they need, beside
+                // the other lanes' ordinary ones.  rsA: p | p0 << 5 | has right << 10 | has left << 11 |
+                // {right, left} lookup from its second bucket << 12 | merged << 16 (never 0 in a repeat); rsB: sr | sl << 16.
+                uint32_t rsA = 0, rsB = 0;
                 for (;;) {
+#if HUTK_MERGE_STAMPS
+                    const long long tt0 = clock64();
+                    long long tt1 = tt0, tt2 = tt0;
+#endif
+#if HUTK_PUBLISH_LATE
+                    have = have && (best != NOKEY || rsA != 0);
+#else
+                    if (have && best == NOKEY && rsA == 0) {  // done: publish the surviving units (unit 0 is in livem already)
+                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                        if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
+                        if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                        have = false;
+                    }
+#endif
+                    if (!__any(have)) break;
+                    if (have) {
+                        int p, p0;
+                        uint32_t merged, sr, sl, b1, b2, t1, t2, second = 0;
+                        bool right, left;
+                        if (rsA == 0) {
+                            p = (int)(best & 31u);
+                            merged = best >> 5;
+                            const uint32_t above = live & ~((2u << p) - 1u);  // not empty: bit p of cand was set
+                            const int q = __builtin_ctz(above);               // the unit the merge consumes
+                            Sw[p] = (SymT)merged;
+                            live &= ~(1u << q);
+                            const uint32_t rmask = above & (above - 1u);    // live units after q
+                            const uint32_t lmask = live & ((1u << p) - 1u);  // live units before p: none iff p == 0
+                            right = rmask != 0;
+                            left = lmask != 0;
+                            const int q2 = __builtin_ctz(rmask | 0x80000000u);
+                            p0 = 31 - __builtin_clz(lmask | 1u);            // == p when there is none
+                            sr = Sw[q2];
+                            sl = Sw[p0];                                      // (read and looked up even when absent)
+                            t1 = pair_mix(merged, sr);
+                            t2 = pair_mix(sl, merged);
+                            b1 = pair_bucket1(t1, T.pair_shift);
+                            b2 = pair_bucket1(t2, T.pair_shift);
+                            cand &= ~((1u << q) | (1u << p) | (1u << p0));
+                        } else {
+                            p = (int)(rsA & 31u);
+                            p0 = (int)((rsA >> 5) & 31u);
+                            right = (rsA >> 10) & 1u;
+                            left = (rsA >> 11) & 1u;
+                            second = (rsA >> 12) & 3u;
+                            merged = rsA >> 16;
+                            sr = rsB & 0xFFFFu;
+                            sl = rsB >> 16;
+                            t1 = pair_mix(merged, sr);
+                            t2 = pair_mix(sl, merged);
+                            b1 = (second & 1u) ? pair_bucket2(t1, T.pair_shift) : pair_bucket1(t1, T.pair_shift);
+                            b2 = (second & 2u) ? pair_bucket2(t2, T.pair_shift) : pair_bucket1(t2, T.pair_shift);
+                        }
+                        const uint4 e1 = T.pair_buckets[b1], e2 = T.pair_buckets[b2];
+#if HUTK_MERGE_STAMPS
+                        tt1 = clock64();
+#endif
+                        if (rsA == 0) best = scan_key(cand);  // (a repeating lane's rescan is done)
+#if HUTK_MERGE_STAMPS
+                        tt2 = clock64();
+#endif
+                        const uint32_t y1 = pair_match(e1, merged | ((sr & 0xFFFu) << 20), sr >> 12);
+                        const uint32_t y2 = pair_match(e2, sl | ((merged & 0xFFFu) << 20), merged >> 12);
+                        const uint32_t f1 = (e1.y >> 28) | ((e1.w >> 28) << 4), f2 = (e2.y >> 28) | ((e2.w >> 28) << 4);
+                        const bool need1 = right && y1 == 0xFFFFFFFFu && !(second & 1u) && ((f1 >> (t1 & 7u)) & 1u);
+                        const bool need2 = left && y2 == 0xFFFFFFFFu && !(second & 2u) && ((f2 >> (t2 & 7u)) & 1u);
+                        if (need1 || need2) {
+                            second |= (need1 ? 1u : 0u) | (need2 ? 2u : 0u);
+                            rsA = (uint32_t)p | ((uint32_t)p0 << 5) | ((right ? 1u : 0u) << 10) | ((left ? 1u : 0u) << 11) |
+                                  (second << 12) | (merged << 16);
+                            rsB = sr | (sl << 16);
+                        } else {
+                            rsA = 0;
+                            uint32_t mr = (y1 >> 8) & 0xFFFFFu, ml = (y2 >> 8) & 0xFFFFFu;
+                            mr = (right && mr != PAIR_ABSENT) ? mr : SYM_NONE;
+                            ml = (left && ml != PAIR_ABSENT) ? ml : SYM_NONE;
+                            Mw[p0] = (SymT)ml;  // first: without a left neighbour p0 == p
+                            Mw[p] = (SymT)mr;
+                            const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
+                            cand |= ((hr ? 1u : 0u) << p) | ((hl ? 1u : 0u) << p0);
+                            const uint32_t kr = hr ? ((mr << 5) | (uint32_t)p) : NOKEY;
+                            const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
+                            best = min(best, min(kr, kl));
+                        }
+                    }
+#if HUTK_MERGE_STAMPS
+                    {   // lane 0's view of the trip (it holds the pool's longest word)
+                        const long long tt3 = clock64();
+                        ts_issue += tt1 - tt0; ts_scan += tt2 - tt1; ts_resolve += tt3 - tt2; ts_trips++;
+                    }
+#endif
+                }
+#else
+                for (;;) {
+#if HUTK_MERGE_STAMPS
+                    const long long tt0 = clock64();
+                    long long tt1 = tt0, tt2 = tt0;
+#endif
+#if HUTK_PUBLISH_LATE
+                    have = have && best != NOKEY;
+#else
                     if (have && best == NOKEY) {  // done: publish the surviving units (unit 0 is in livem already)
                         const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
                         if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
                         if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
                         have = false;
                     }
+#endif
                     if (!__any(have)) break;
                     if (have) {
                         const int p = (int)(best & 31u);
@@ -857,8 +1038,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         const uint32_t sr = Sw[q2], sl = Sw[p0];         // (read and looked up even when absent)
                         const PairProbe s1 = pair_issue(T, merged, sr);
                         const PairProbe s2 = pair_issue(T, sl, merged);
+#if HUTK_MERGE_STAMPS
+                        tt1 = clock64();
+#endif
                         cand &= ~((1u << q) | (1u << p) | (1u << p0));
                         best = scan_key(cand);
+#if HUTK_MERGE_STAMPS
+                        tt2 = clock64();
+#endif
                         uint32_t mr = pair_resolve(T, s1, merged, sr), ml = pair_resolve(T, s2, sl, merged);
                         mr = right ? mr : SYM_NONE;
                         ml = left ? ml : SYM_NONE;
@@ -870,6 +1057,24 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
                         best = min(best, min(kr, kl));
                     }
+#if HUTK_MERGE_STAMPS
+                    {   // lane 0's view of the trip (it holds the pool's longest word)
+                        const long long tt3 = clock64();
+                        ts_issue += tt1 - tt0; ts_scan += tt2 - tt1; ts_resolve += tt3 - tt2; ts_trips++;
+                    }
+#endif
+                }
+#endif
+#if HUTK_MERGE_STAMPS
+                if (first_epoch && base == 64u * wv && tile_ok && W.prof && lane == 0) {
+                    W.prof[tile * N_PHASE + 7] = ts_issue; W.prof[tile * N_PHASE + 8] = ts_scan;
+                    W.prof[tile * N_PHASE + 9] = ts_resolve | (ts_trips << 40);
+                }
+#endif
+                if (HUTK_PUBLISH_LATE && mine) {  // publish the surviving units (unit 0 is in livem already)
+                    const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                    if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
+                    if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
                 }
                 wave_sync();
             } else {
@@ -1003,9 +1208,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         first_epoch = false;
         if (!again) break;
     }
-    HUTK_MSTAMP(7);
-    HUTK_MSTAMP(8);
-    HUTK_MSTAMP(9);
     if (tile_ok) HUTK_STAMP(5);
 
     if (!tile_ok) return;

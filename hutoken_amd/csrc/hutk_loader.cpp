@@ -214,6 +214,7 @@ LoadError finish_pair_table(Tables& T, const std::vector<uint64_t>& entries_in) 
     std::stable_sort(entries.begin(), entries.end(),
                      [](uint64_t x, uint64_t y) { return (x >> 40) < (y >> 40); });
     uint32_t n_buckets = pow2_at_least(entries.size() * 5 / 4 + 16);  // two entries each: load <= 0.4
+    if (const char* e = getenv("HUTK_PAIR_BUCKETS_LOG2")) n_buckets = 1u << atoi(e);  // measurement: footprint against probes
     for (int attempt = 0;; attempt++) {
         int64_t n_second_extra = 0;
         uint32_t shift = 32;

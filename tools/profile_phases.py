@@ -39,10 +39,19 @@ for nme, v in zip(names, ph):
 if os.environ.get("HUTK_MERGE_STAMPS_BUILD"):
     # a -DHUTK_MERGE_STAMPS=1 build: the stamps are inside the merge phase; per wavefront of the workgroup
     raw = ctx.profile_raw(n_tiles)[: n_tiles // 4 * 4].reshape(-1, 4, 10)
-    names = ["barrier 1 (wait)", "pool fill", "barrier 2 (wait)", "set-up", "trips", "barrier 3 (wait)", "tail"]
+    names = ["barrier 1 (wait)", "pool fill", "barrier 2 (wait)", "set-up", "trips", "barrier 3 (wait)"]
     for wv in range(4):
-        dlt = np.diff(raw[:, wv, :8], axis=1).mean(axis=0)
+        dlt = np.diff(raw[:, wv, :7], axis=1).mean(axis=0)
         print(f"  wavefront {wv}: " + "  ".join(f"{n} {v:.0f}" for n, v in zip(names, dlt)))
-    span = (raw[:, :, 7].max(axis=1) - raw[:, :, 0].min(axis=1)).mean()
+    span = (raw[:, :, 6].max(axis=1) - raw[:, :, 0].min(axis=1)).mean()
     print(f"  workgroup: first arrival to last exit {span:.0f} cycles")
+    simd = raw[:, :, 0] & 3
+    print("  SIMD of wavefront 0..3 of a workgroup, share of workgroups: " +
+          "  ".join("wv%d %s" % (w, np.round(np.bincount(simd[:, w], minlength=4) / len(simd), 2).tolist()) for w in range(4)))
+    w0 = raw[:, 0, :]  # the wavefront with the pool's longest words: lane 0's clock inside the trips
+    trips = (w0[:, 9] >> 40).astype(np.float64)
+    res = (w0[:, 9] & ((1 << 40) - 1)).astype(np.float64)
+    ok = trips > 0
+    print(f"  wavefront 0 trips: {trips[ok].mean():.1f} per workgroup; per trip: apply+issue {(w0[ok, 7] / trips[ok]).mean():.0f}  "
+          f"rescan {(w0[ok, 8] / trips[ok]).mean():.0f}  wait+resolve+store {(res[ok] / trips[ok]).mean():.0f} cycles")
 ctx.profile(False)
