@@ -79,6 +79,7 @@ struct hutk_ctx {
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<WordSlot> d_word_tab;
+    DevBuf<WordSlotLong> d_wordl_tab;
     int64_t n_word_entries = 0;
     DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
     DevBuf<long long> w_prof;
@@ -218,6 +219,8 @@ int upload_tables(hutk_ctx* c) {
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
     D.word_tab = nullptr;
     D.word_mask = 0;
+    D.wordl_tab = nullptr;
+    D.wordl_mask = 0;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
     // context: merge its units once, on the device, with the batch path's own loop
@@ -357,7 +360,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_tab.release(); c->w_wbits.release(); c->w_gbits.release();
+        c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release(); c->w_defer.release();
         c->w_exc.release(); c->w_exc_long.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
@@ -404,11 +407,36 @@ int build_word_table(hutk_ctx* c) {
     c->dt.has_prefix = had_prefix;
     if (rc) return rc;
     const int64_t key_bytes = T.sym16 ? WORD_KEY_BYTES_16 : WORD_KEY_BYTES_32;  // (WordSlot, hutk_device.h)
-    std::vector<size_t> keep;
+    std::vector<size_t> keep, keep_long;
     for (size_t i = 0; i < n; i++)
-        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2 &&
-            offs[i + 1] - offs[i] <= key_bytes)
-            keep.push_back(i);
+        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
+            (offs[i + 1] - offs[i] <= key_bytes ? keep : keep_long).push_back(i);
+    auto key_of = [&](size_t i) {
+        uint32_t k[4] = {0, 0, 0, 0};
+        const size_t len = (size_t)(offs[i + 1] - offs[i]);
+        for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
+        return make_uint4(k[0], k[1], k[2], k[3]);
+    };
+    if (!keep_long.empty() && !T.is_byte_encoder) {  // the companion table (WordSlotLong), see k_tiles for when it pays
+        std::vector<uint4> kk(keep_long.size());
+        for (size_t q = 0; q < keep_long.size(); q++) kk[q] = key_of(keep_long[q]);
+        // ONE slot per word (hash & mask), first come first served in vocabulary order; a word that finds its slot
+        // taken is left out and goes through the merge loop as before (the table is 8 x the words: about 1 in 17)
+        uint32_t cap = 256;
+        while (cap < keep_long.size() * 8 + 16) cap <<= 1;
+        std::vector<WordSlotLong> slots(cap + 1, WordSlotLong{{0, 0, 0, 0}, 0});
+        for (size_t j = 0; j < keep_long.size(); j++) {
+            const uint4 k = kk[j];
+            WordSlotLong& sl = slots[word_hash(k.x, k.y, k.z, k.w) & (cap - 1)];
+            if (sl.k[0] | sl.k[1] | sl.k[2] | sl.k[3]) continue;
+            sl = WordSlotLong{{k.x, k.y, k.z, k.w}, T.cand_sym[keep_long[j]]};
+            c->n_word_entries++;
+        }
+        HIP_TRY(c->d_wordl_tab.reserve(slots.size()));
+        HIP_TRY(hipMemcpy(c->d_wordl_tab.p, slots.data(), slots.size() * sizeof(WordSlotLong), hipMemcpyHostToDevice));
+        c->dt.wordl_tab = c->d_wordl_tab.p;
+        c->dt.wordl_mask = cap - 1;
+    }
     if (keep.empty()) return HUTK_OK;
     // two-choice cuckoo table of 16-byte slots (hutk_device.h); a word that cannot be placed is simply left out
     std::vector<uint4> kk(keep.size());
@@ -438,7 +466,7 @@ int build_word_table(hutk_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_word_tab.p, slots.data(), slots.size() * sizeof(WordSlot), hipMemcpyHostToDevice));
     c->dt.word_tab = c->d_word_tab.p;
     c->dt.word_mask = cap - 1;
-    c->n_word_entries = (int64_t)placed;
+    c->n_word_entries += (int64_t)placed;
     return HUTK_OK;
 }
 

@@ -275,10 +275,17 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //   HUTK_FAST_MERGE   0: the general merge loop also where the short form (packed keys) applies
 //   HUTK_STAGE_RUN    1: a tile's symbols go to HBM through LDS as 16-byte stores instead of lane by lane (measured: -1 %)
 //   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
-//   HUTK_SCAN_RAW     1: the rescan takes "no candidate left" as index -1 (v_ffbl's answer for 0), whose key is all ones:
-//                     25 instead of 37 VALU instructions per four candidates; measured -0.4 % alone
-//   HUTK_PUBLISH_LATE 1: a word's surviving units are published after the trip loop instead of in the trip it ends in;
-//                     measured +0.4 % alone, -3 % together with HUTK_SCAN_RAW
+//   HUTK_SCAN_RAW     1 (default): the rescan takes "no candidate left" as index -1 (v_ffbl's answer for 0), whose key is
+//                     all ones: 25 instead of 37 VALU instructions per four candidates
+//   HUTK_PUBLISH_LATE 1 (default): a word's surviving units are published after the trip loop, not in the trip it ends in
+//   HUTK_LANE_RETRY   1 (default): a pair lookup that must go on in its second bucket is repeated by ITS lane in the next
+//                     trip instead of making the whole wavefront wait for a second round trip inside the trip.
+//                     The three together, 200 k documents on one box: C3 164.8 -> 169.1, C2 185.0 -> 188.8 GB/s; random
+//                     17-31-letter words (every lane busy in every trip) 66.3 -> 60.8.  Each alone: within +-1 %.
+//   HUTK_WORD_SECOND_LATE 1: the whole-word table's second slot only for lanes that missed in the first (+-0 %)
+//   HUTK_NT_STREAM    1: non-temporal loads of the input and stores of the run (-2.5 %)
+//   HUTK_PERTURB_VALU / _SLEEP / _MEM: MEASUREMENT ONLY, extra VALU instructions / idle cycles / 16-byte gathers per
+//                     tile: what the kernel's time responds to
 //   HUTK_MERGE_STAMPS 1: MEASUREMENT ONLY, the clock stamps are spent inside the merge phase
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
@@ -298,6 +305,12 @@ static_assert(NPOS == 64 * 16, "16 positions per lane");
 #ifndef HUTK_PERTURB_VALU
 #define HUTK_PERTURB_VALU 0
 #endif
+#ifndef HUTK_WORD_SECOND_LATE
+#define HUTK_WORD_SECOND_LATE 0
+#endif
+#ifndef HUTK_NT_STREAM
+#define HUTK_NT_STREAM 0
+#endif
 #ifndef HUTK_PERTURB_MEM
 #define HUTK_PERTURB_MEM 0
 #endif
@@ -308,10 +321,10 @@ static_assert(NPOS == 64 * 16, "16 positions per lane");
 #define HUTK_LANE_RETRY 1
 #endif
 #ifndef HUTK_SCAN_RAW
-#define HUTK_SCAN_RAW 0
+#define HUTK_SCAN_RAW 1
 #endif
 #ifndef HUTK_PUBLISH_LATE
-#define HUTK_PUBLISH_LATE 0
+#define HUTK_PUBLISH_LATE 1
 #endif
 #ifndef HUTK_MERGE_STAMPS
 #define HUTK_MERGE_STAMPS 0  // 1: MEASUREMENT ONLY, the ten clock stamps are spent inside the merge phase (tools/profile_phases.py)
@@ -504,7 +517,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         for (int c = lane; c < WINDOW / 16; c += 64) {
             const int64_t p = gw + 16 * c;
             if (p >= 0 && p + 16 <= A.n_bytes) {
+#if HUTK_NT_STREAM
+                typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<v4u*>(sb + 16 * c) = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(A.bytes + p));
+#else
                 *reinterpret_cast<uint4*>(sb + 16 * c) = *reinterpret_cast<const uint4*>(A.bytes + p);
+#endif
             } else {
                 for (int k = 0; k < 16; k++) {
                     const int64_t q = p + k;
@@ -666,10 +684,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const uint32_t h1 = probe ? wh & T.word_mask : 0u;
                 const uint32_t h2 = probe ? word_slot2(wh, T.word_mask) : 0u;
                 uint4 s1 = make_uint4(0, 0, 0, 0), s2 = s1;
+                WordSlotLong l1{};
+                // (the companion table exists outside byte-encoder mode only: measured on C3 x VG it costs 1.4 % and finds
+                // next to nothing, on C5 x VL -- two-byte characters, longer words -- it is worth 13 %)
+                const bool probe_long = !BYTE_MODE && !gap && !exc && !pfx && T.wordl_mask && nb > WORD_KEY && nb <= 16;
                 uint32_t isym = 0;
                 if (T.word_mask) {  // uniform
                     s1 = reinterpret_cast<const uint4*>(T.word_tab)[h1];
+#if !HUTK_WORD_SECOND_LATE
                     s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
+#endif
+                }
+                if (!BYTE_MODE && T.wordl_mask && __any(probe_long)) {  // (uniform; many rounds have no such word)
+                    if (probe_long) l1 = T.wordl_tab[wh & T.wordl_mask];  // ONE choice: see build_word_table
                 }
                 if (BYTE_MODE) isym = T.item_sym[b0];
 #if HUTK_PERTURB_MEM
@@ -688,12 +715,25 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     // bitwise on purpose: with && the compiler fetches one word first and the rest only on a match
                     // (the probed word's bytes beyond WORD_KEY are zero: k3 has nothing in the symbol's place)
                     constexpr int KSH = sizeof(SymT) == 2 ? 16 : 32;  // bits of k[3] that are symbol, not key
-                    const uint32_t d1 = KSH == 32 ? 0u : (s1.w ^ k3) << (KSH & 31), d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
+                    const uint32_t d1 = KSH == 32 ? 0u : (s1.w ^ k3) << (KSH & 31);
+#if !HUTK_WORD_SECOND_LATE
+                    const uint32_t d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
+#endif
                     const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2) | d1) == 0;
+#if HUTK_WORD_SECOND_LATE
+                    // the second slot only for the lanes whose word is not in its first: a second round trip for the round,
+                    // but a third fewer gather accesses (the builder gives a word its first slot whenever that is free)
+                    if (!hit1) s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
+                    const uint32_t d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
+#endif
                     const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2) | d2) == 0;
                     done = hit1 || hit2;
                     const uint32_t sw = hit1 ? s1.w : s2.w;
                     if (done) S[ws] = Sym<SymT>::narrow(KSH == 32 ? sw : sw >> (KSH & 31));
+                }
+                if (probe_long) {
+                    done = ((l1.k[0] ^ k0) | (l1.k[1] ^ k1) | (l1.k[2] ^ k2) | (l1.k[3] ^ k3)) == 0;
+                    if (done) S[ws] = Sym<SymT>::narrow(l1.sym);
                 }
                 int n = 0;
                 SymT* Sdst = S + ws;
@@ -1331,7 +1371,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 pos += n;
                 continue;
             }
+#if HUTK_NT_STREAM
+            if ((live16 >> j) & 1u) __builtin_nontemporal_store(S[ws], &dst[pos++]);
+#else
             if ((live16 >> j) & 1u) dst[pos++] = S[ws];  // stores only: nothing here waits
+#endif
         }
     };
     if (DEFER) {

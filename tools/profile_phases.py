@@ -10,7 +10,11 @@ n_docs = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 vocab = sys.argv[3] if len(sys.argv) > 3 else "VG"
 vp, sp, kw = data.vocab_files(vocab)
 ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
-d, o = synth.corpus(name, n_docs)
+if name.startswith("words:"):  # words:LO:HI -- random words of LO..HI letters (every word through the merge loop / exception kernels)
+    lo, hi = (int(x) for x in name.split(":")[1:3])
+    d, o = synth.random_words(lo, hi, n_docs, 8)
+else:
+    d, o = synth.corpus(name, n_docs)
 dev = torch.device("cuda", 0)
 db, do = torch.from_numpy(d).to(dev), torch.from_numpy(o).to(dev)
 cap = ctx.ids_capacity(len(d), n_docs)
