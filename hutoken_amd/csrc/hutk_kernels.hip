@@ -282,6 +282,7 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //                     trip instead of making the whole wavefront wait for a second round trip inside the trip.
 //                     The three together, 200 k documents on one box: C3 164.8 -> 169.1, C2 185.0 -> 188.8 GB/s; random
 //                     17-31-letter words (every lane busy in every trip) 66.3 -> 60.8.  Each alone: within +-1 %.
+//   HUTK_TRIP_PRIO     n: s_setprio(n) around the merge trips (+-0 %)
 //   HUTK_WORD_SECOND_LATE 1: the whole-word table's second slot only for lanes that missed in the first (+-0 %)
 //   HUTK_NT_STREAM    1: non-temporal loads of the input and stores of the run (-2.5 %)
 //   HUTK_PERTURB_VALU / _SLEEP / _MEM: MEASUREMENT ONLY, extra VALU instructions / idle cycles / 16-byte gathers per
@@ -304,6 +305,9 @@ static_assert(NPOS == 64 * 16, "16 positions per lane");
 
 #ifndef HUTK_PERTURB_VALU
 #define HUTK_PERTURB_VALU 0
+#endif
+#ifndef HUTK_TRIP_PRIO
+#define HUTK_TRIP_PRIO 0
 #endif
 #ifndef HUTK_WORD_SECOND_LATE
 #define HUTK_WORD_SECOND_LATE 0
@@ -946,6 +950,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_MERGE_STAMPS
                 long long ts_issue = 0, ts_scan = 0, ts_resolve = 0, ts_trips = 0;
 #endif
+#if HUTK_TRIP_PRIO
+                // The trips are one dependent chain per wavefront (~75 VALU instructions and a table round trip each) and the
+                // rest of the workgroup waits for the longest: their instructions go ahead of the other wavefronts' on the SIMD
+                __builtin_amdgcn_s_setprio(HUTK_TRIP_PRIO);
+#endif
 #if HUTK_LANE_RETRY
                 // A lookup that must go on in the pair's SECOND bucket (a filter bit of the first one says so; under 1 % of
                 // the lookups) is not followed up inside the trip: with 64 lanes and two lookups each, nearly every trip
@@ -1104,6 +1113,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     }
 #endif
                 }
+#endif
+#if HUTK_TRIP_PRIO
+                __builtin_amdgcn_s_setprio(0);
 #endif
 #if HUTK_MERGE_STAMPS
                 if (first_epoch && base == 64u * wv && tile_ok && W.prof && lane == 0) {
