@@ -39,7 +39,7 @@ EMOJI = "😂🙂🚀"
 ODD = " €—…«»"
 
 
-def random_byte_vocab(seed, n_merges=300, proper=True, dup_ids=False, neg_ids=False):
+def random_byte_vocab(seed, n_merges=300, proper=True, dup_ids=False, neg_ids=False, max_len=12):
     """GPT-2-shaped byte-level vocabulary: 256 byte tokens then `n_merges`
     tokens that are concatenations of two earlier tokens (proper=True) or
     arbitrary short byte strings with shuffled ids (proper=False).
@@ -53,14 +53,14 @@ def random_byte_vocab(seed, n_merges=300, proper=True, dup_ids=False, neg_ids=Fa
     seen = set(raw_tokens)
     while len(raw_tokens) < 256 + n_merges:
         if proper:
-            a = rng.choice(raw_tokens[: max(256, len(raw_tokens))])
+            a = raw_tokens[rng.randrange(len(raw_tokens))]
             b = rng.choice(raw_tokens)
             if rng.random() < 0.7:
                 a = bytes([rng.choice(alphabet)]) if rng.random() < 0.5 else a
             tok = a + b
         else:
             tok = bytes(rng.choice(alphabet) for _ in range(rng.randint(2, 5)))
-        if tok in seen or len(tok) > 12:
+        if tok in seen or len(tok) > max_len:
             continue
         seen.add(tok)
         raw_tokens.append(tok)
@@ -80,7 +80,7 @@ def random_byte_vocab(seed, n_merges=300, proper=True, dup_ids=False, neg_ids=Fa
     return entries, vf.gpt2_special_mapping()
 
 
-def random_char_vocab(seed, n_merges=300, drop_chars=""):
+def random_char_vocab(seed, n_merges=300, drop_chars="", max_len=10):
     """SentencePiece/Llama-shaped vocabulary (is_byte_encoder=False,
     prefix U+2581): single characters, byte-fallback literals <0xHH>, and
     merges of earlier tokens.  Characters in `drop_chars` are left out so that
@@ -95,7 +95,7 @@ def random_char_vocab(seed, n_merges=300, drop_chars=""):
         a = rng.choice(base if rng.random() < 0.5 else toks[256:])
         b = rng.choice(base if rng.random() < 0.5 else toks[256:])
         tok = a + b
-        if tok in seen or len(tok) > 10:
+        if tok in seen or len(tok) > max_len:
             continue
         seen.add(tok)
         toks.append(tok)
