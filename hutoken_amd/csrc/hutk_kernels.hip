@@ -633,11 +633,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
         uint32_t nW;
         const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
+        uint32_t rest = own, widx = wbase;  // my word starts not yet handed out, and the index of the first of them
         for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
-            {
-                uint32_t wi = wbase - r0;
-                for (uint32_t m = own; m; m &= m - 1, wi++)
-                    if (wi < 64u) stage[wi] = (uint16_t)(16 * lane + __builtin_ctz(m));
+            while (rest && widx - r0 < 64u) {  // (each start is visited once, in the round it belongs to)
+                stage[widx - r0] = (uint16_t)(16 * lane + __builtin_ctz(rest));
+                rest &= rest - 1;
+                widx++;
             }
             wave_sync();
             if (r0 + lane < nW) {
