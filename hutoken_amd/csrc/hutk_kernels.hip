@@ -306,6 +306,9 @@ static_assert(NPOS == 64 * 16, "16 positions per lane");
 #ifndef HUTK_PERTURB_VALU
 #define HUTK_PERTURB_VALU 0
 #endif
+#ifndef HUTK_FAST_TRIPS_ANY_MODE
+#define HUTK_FAST_TRIPS_ANY_MODE 1  // the short form's trips outside byte-encoder mode too (rank == symbol order, 16-bit symbols)
+#endif
 #ifndef HUTK_TRIP_PRIO
 #define HUTK_TRIP_PRIO 0
 #endif
@@ -412,6 +415,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #endif
     // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
     constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
+    // ... whose trips (not its set-up, which reads the (byte, next byte) table) serve the other mode as well
+    constexpr bool FAST_TRIPS = HUTK_FAST_MERGE && HUTK_FAST_TRIPS_ANY_MODE ? (RANK_IS_SYM && sizeof(SymT) == 2) : FAST;
     // ... and then the merge loop is not run here at all: a word that needs it RESERVES one slot per unit in the
     // tile's run, leaves its start and unit count in the first two, and k_merge fills the slots in (see there)
     constexpr bool DEFER = FAST && KEEP < LANE_MAX_UNITS;
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         if (first_epoch && tile_ok && W.prof && lane == 0)  // the SIMD this wavefront runs on (HW_ID bits 5:4) in the stamp's low bits
             W.prof[tile * N_PHASE + 0] = (clock64() & ~3ll) | (long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 #endif
-        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = (FAST && HUTK_SCAN_RAW) ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
+        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = (FAST_TRIPS && HUTK_SCAN_RAW) ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
         __syncthreads();
         if (first_epoch) HUTK_MSTAMP(1);
         uint32_t pending = 0;
@@ -881,8 +886,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                             arena_slot = a;
                         }
             }
-            if constexpr (FAST) {
-                // Byte-encoder mode, 16-bit symbols, rank == symbol order.  A pair is the 32-bit KEY
+            if constexpr (FAST_TRIPS) {
+                // 16-bit symbols, rank == symbol order.  A pair is the 32-bit KEY
                 // merged symbol << 5 | position: the smallest key is the pair of minimal rank, leftmost on
                 // ties (queue.c:162-164), so the best pair is one register and every comparison a v_min.
                 constexpr uint32_t NOKEY = 0xFFFFFFFFu;
@@ -907,7 +912,38 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     }
                     return b;
                 };
-                if (have) {
+                auto publish = [&]() {  // the surviving units (unit 0 is in livem already); arena words keep theirs apart
+                    if (!BYTE_MODE && arena_slot >= 0) {
+                        X.arena_live[arena_slot] = live;
+                        return;
+                    }
+                    const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
+                    if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
+                    if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                };
+                if (have && !BYTE_MODE) {
+                    // the symbols are in place (phase 5); the pair results of neighbours: four lookups (eight loads) in flight
+                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+                    for (int i0 = 0; i0 + 1 < n; i0 += 4) {
+                        PairProbe pr[4];
+                        uint32_t sy[5];
+#pragma unroll
+                        for (int j = 0; j < 5; j++) sy[j] = (i0 + j < n) ? (uint32_t)Sw[i0 + j] : 0u;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int i = i0 + j;
+                            if (i + 1 < n) {
+                                const uint32_t m = pair_resolve(T, pr[j], sy[j], sy[j + 1]);
+                                Mw[i] = (SymT)m;
+                                if (m != SYM_NONE) cand |= 1u << i;
+                            }
+                        }
+                    }
+                    best = scan_key(cand);
+                }
+                if (have && BYTE_MODE) {
                     live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
                     // Set-up, eight units per step and no branch per unit: the word's bytes come out of LDS as three
                     // aligned dwords; two consecutive bytes are the index of the (byte, next byte) table, whose
@@ -973,9 +1009,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     have = have && (best != NOKEY || rsA != 0);
 #else
                     if (have && best == NOKEY && rsA == 0) {  // done: publish the surviving units (unit 0 is in livem already)
-                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
-                        if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
-                        if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                        publish();
                         have = false;
                     }
 #endif
@@ -1067,9 +1101,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     have = have && best != NOKEY;
 #else
                     if (have && best == NOKEY) {  // done: publish the surviving units (unit 0 is in livem already)
-                        const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
-                        if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
-                        if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                        publish();
                         have = false;
                     }
 #endif
@@ -1125,9 +1157,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 }
 #endif
                 if (HUTK_PUBLISH_LATE && mine) {  // publish the surviving units (unit 0 is in livem already)
-                    const uint64_t lm = (uint64_t)(live & ~1u) << (ws & 31);
-                    if ((uint32_t)lm) atomicOr(&X.livem[ws >> 5], (uint32_t)lm);
-                    if ((uint32_t)(lm >> 32)) atomicOr(&X.livem[(ws >> 5) + 1], (uint32_t)(lm >> 32));
+                    publish();
                 }
                 wave_sync();
             } else {
