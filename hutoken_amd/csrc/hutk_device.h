@@ -106,9 +106,8 @@ struct Workspace {
     int64_t n_scan_blocks;
     uint32_t* doc_tile_pos;    // [n_docs + 1] ids the owning tile emits before the document start
     ExcRec* exc;               // [cap_exc]
-    uint32_t* exc_long;        // [cap_exc] records k_exc_medium left (count: counters[3]); the ends pass splits them:
-    uint32_t* exc_quad;        // [cap_exc] ... words of at most 256 units for k_exc_quad (count: counters[4])
-    uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in k_exc (count: counters[5])
+    uint32_t* exc_quad;        // [cap_exc] exception words of at most 256 units for d_exc_quad (count: counters[4])
+    uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in d_exc (count: counters[5])
     uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
     uint32_t* tile_ndefer;     // [n_tiles] words of the tile that k_merge encodes
