@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd "$ROOT"
 SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_DATA_STALL_CYCLES_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG")
+if [ -n "$PMC_SETS" ]; then IFS=';' read -r -a SETS <<< "$PMC_SETS"; fi  # e.g. PMC_SETS="SQ_INSTS_VALU SQ_INSTS_SALU;TA_BUSY_avr"
 for lib in "$@"; do
   export HUTOKEN_AMD_LIB=$ROOT/$lib
   name=$(basename $lib .so)
