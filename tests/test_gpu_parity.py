@@ -327,6 +327,29 @@ def test_python_surface(vg_files, oracle_mod):
     assert hutoken.batch_encode(["ab\0cd"]) == [orc.encode("ab")]
 
 
+def test_python_surface_with_several_devices(vg_files, oracle_mod, monkeypatch):
+    """initialize(..., devices=[...]) and HUTOKEN_DEVICES: batch_encode spreads the list over the device contexts."""
+    import hutoken_amd as hutoken
+    from hutoken_amd import synth
+    vp, sp, kw = vg_files
+    monkeypatch.setenv("HUTK_MULTI_MIN_BYTES", "0")
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C3", 1500, first_doc=7000)
+    docs = synth.docs_as_str(d, o)
+    want = orc.batch_encode(docs, 8)
+    hutoken.initialize(vp, sp, devices=[0, 0, 0], **kw)
+    assert hutoken._ctx.device_count == 3
+    assert hutoken.batch_encode(docs, 4) == want
+    assert hutoken.encode(docs[3]) == want[3]
+    monkeypatch.setenv("HUTOKEN_DEVICES", "0,0")
+    hutoken.initialize(vp, sp, **kw)
+    assert hutoken._ctx.device_count == 2
+    assert hutoken.batch_encode(docs, 4) == want
+    monkeypatch.delenv("HUTOKEN_DEVICES")
+    hutoken.initialize(vp, sp, **kw)
+    assert hutoken._ctx.device_count == 1
+
+
 def test_two_streams_and_two_threads_on_one_context(vg_files, oracle_mod):
     """Calls on one context are serialised (a mutex on the host, an event on the device): launches on two streams without
     any synchronisation in between, and host calls from two threads, give the same ids as one call after the other."""
