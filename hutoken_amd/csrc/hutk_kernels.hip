@@ -2271,12 +2271,19 @@ __device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& 
     }
 }
 
+// The splitter's window of a wavefront: word starts of EXC_CHUNK positions from `base`, computed with the bytes of document
+// `doc` (the others read as zero), one bit per position.  Exception words of one tile follow each other closely, so the
+// window that held one word's end usually holds the next one's as well and is not staged again.
+struct EndsWin {
+    int64_t base = -1, doc = -1;
+    unsigned long long bits[EXC_CHUNK / 64];
+};
 // End of a word whose end its tile could not see (more than 63 bytes, or beyond the tile's window): the splitter's rule
 // applied 256 positions at a time (src/parser.c:24-183 as in k_tiles' exact form), or -- regex pre-token path -- the next
-// start bit of the host's bitmap.  One wavefront; sb / scode / docm are its LDS scratch.  -> end offset; *too_large when
-// the word passes the reference's limit (core.c:402-407).
-__device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t ds, int64_t de, uint8_t* sb, uint8_t* scode,
-                                uint32_t* docm, int lane, bool* too_large) {
+// start bit of the host's bitmap.  One wavefront; sb / scode / docm are its LDS scratch, cw its window (above).
+// -> end offset; *too_large when the word passes the reference's limit (core.c:402-407).
+__device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t d, int64_t ds, int64_t de, uint8_t* sb, uint8_t* scode,
+                                uint32_t* docm, int lane, bool* too_large, EndsWin& cw) {
     int64_t we = -1;
     *too_large = false;
     if (A.word_bits) {
@@ -2296,30 +2303,43 @@ __device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t ds, int6
         if (we - ws > MAX_WORD_BYTES) *too_large = true;
         return we;
     }
-    for (int64_t base = ws + 1; we < 0; base += EXC_CHUNK) {
-        if (base - ws > MAX_WORD_BYTES + 1) { *too_large = true; break; }
-        const int64_t g0 = base - 16;  // global offset of window index 0
-        for (int i = lane; i < EXC_WIN; i += 64) {
-            const int64_t q = g0 + i;
-            sb[i] = (q >= ds && q < de) ? A.bytes[q] : (uint8_t)0;
+    for (int64_t pos = ws + 1; we < 0;) {  // (every value here is the same in all lanes)
+        if (pos - ws > MAX_WORD_BYTES + 1) { *too_large = true; break; }
+        if (!(cw.doc == d && pos >= cw.base && pos < cw.base + EXC_CHUNK)) {
+            const int64_t base = pos;
+            const int64_t g0 = base - 16;  // global offset of window index 0
+            for (int i = lane; i < EXC_WIN; i += 64) {
+                const int64_t q = g0 + i;
+                sb[i] = (q >= ds && q < de) ? A.bytes[q] : (uint8_t)0;
+            }
+            if (lane < EXC_WIN / 32 + 1) docm[lane] = 0;
+            wave_sync();
+            if (lane == 0) {
+                if (ds >= g0 && ds < g0 + EXC_WIN) docm[(ds - g0) >> 5] |= 1u << ((ds - g0) & 31);
+                if (de >= g0 && de < g0 + EXC_WIN) docm[(de - g0) >> 5] |= 1u << ((de - g0) & 31);
+            }
+            wave_sync();
+            for (int i = lane; i < EXC_WIN; i += 64)
+                scode[i] = (i >= 4 && i < EXC_WIN - 4) ? code_at(sb, docm, i) : (uint8_t)C_BAD;
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < EXC_CHUNK / 64; r++) {
+                const int64_t q = base + 64 * r + lane;
+                cw.bits[r] = __ballot((q <= de) && word_starts(scode, docm, 16 + 64 * r + lane));
+            }
+            wave_sync();
+            cw.base = base;
+            cw.doc = d;
         }
-        if (lane < EXC_WIN / 32 + 1) docm[lane] = 0;
-        wave_sync();
-        if (lane == 0) {
-            if (ds >= g0 && ds < g0 + EXC_WIN) docm[(ds - g0) >> 5] |= 1u << ((ds - g0) & 31);
-            if (de >= g0 && de < g0 + EXC_WIN) docm[(de - g0) >> 5] |= 1u << ((de - g0) & 31);
+        const int rel = (int)(pos - cw.base);
+#pragma unroll
+        for (int r = 0; r < EXC_CHUNK / 64; r++) {
+            if (we >= 0 || 64 * (r + 1) <= rel) continue;
+            unsigned long long m = cw.bits[r];
+            if (rel > 64 * r) m &= ~0ull << (rel - 64 * r);
+            if (m) we = cw.base + 64 * r + __builtin_ctzll(m);
         }
-        wave_sync();
-        for (int i = lane; i < EXC_WIN; i += 64)
-            scode[i] = (i >= 4 && i < EXC_WIN - 4) ? code_at(sb, docm, i) : (uint8_t)C_BAD;
-        wave_sync();
-        for (int r0 = 0; r0 < EXC_CHUNK && we < 0; r0 += 64) {
-            const int64_t q = base + r0 + lane;
-            const bool f = (q <= de) && word_starts(scode, docm, 16 + r0 + lane);
-            const unsigned long long bal = __ballot(f);
-            if (bal) we = base + r0 + __builtin_ctzll(bal);
-        }
-        wave_sync();
+        pos = cw.base + EXC_CHUNK;
     }
     return we;
 }
@@ -2335,7 +2355,7 @@ struct EndsLds {
     uint32_t docm[EXC_WIN / 32 + 1];
     uint32_t lq[ENDS_LIST], lw[ENDS_LIST];
 };
-constexpr uint32_t ENDS_SHARE = 4;  // wavefronts that share the words of one tile (word e goes to wavefront e % ENDS_SHARE)
+constexpr uint32_t ENDS_SHARE = 1;  // wavefronts that share the words of one tile (one: the splitter's window is reused from word to word)
 __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
                                            uint32_t vgrid, uint8_t* lds) {
     EndsLds& L = *reinterpret_cast<EndsLds*>(lds);
@@ -2351,6 +2371,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
         const uint32_t tile = W.exc_tiles[ti];
         const uint32_t first = W.tile_exc_first[tile], nexc = W.tile_nexc[tile];
         uint32_t nq = 0, nw = 0;  // (the same in every lane)
+        EndsWin cw;
         for (uint32_t e = sub; e < nexc; e += ENDS_SHARE) {
             const uint32_t idx = first + e;
             if ((int64_t)idx >= W.cap_exc) break;
@@ -2359,7 +2380,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
             const int64_t ws = rec.ws;
             const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
             bool too_large;
-            const int64_t we = exc_word_end(A, ws, ds, de, sb, scode, docm, lane, &too_large);
+            const int64_t we = exc_word_end(A, ws, d, ds, de, sb, scode, docm, lane, &too_large, cw);
             const int64_t nb = too_large ? 0 : we - ws;
             if (too_large || nb > MAX_WORD_BYTES) {
                 if (lane == 0) {
