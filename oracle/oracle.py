@@ -126,7 +126,10 @@ class Oracle:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().hto_destroy(self._h)
+            try:
+                lib().hto_destroy(self._h)
+            except TypeError:  # interpreter shutdown: the module's globals are gone already
+                pass
             self._h = None
 
     __del__ = close
