@@ -88,13 +88,15 @@ def test_full_size_without_the_whole_word_table(g, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("no_table", [False, True], ids=["table", "no-table"])
+@pytest.mark.parametrize("mode,no_table", [("1", False), ("1", True), ("2", False), ("3", False)],
+                         ids=["all-table", "all-no-table", "over16", "over12"])
 @pytest.mark.parametrize("g", [g for g in g7_cases() if g["vocab"] == "VG"], ids=case_id)
-def test_full_size_with_the_split_merge_kernels(g, no_table, monkeypatch):
+def test_full_size_with_the_split_merge_kernels(g, mode, no_table, monkeypatch):
     """HUTK_SPLIT_MERGE=1: k_tiles leaves the merge loop to k_merge (words sorted by unit count, one per lane) and
-    k_compact; the same ids.  Also without the whole-word table, i.e. with every word going that way."""
+    k_compact; the same ids.  Also without the whole-word table, i.e. with every word going that way, and in the two
+    hybrid modes (2 / 3: only the words of more than 16 / 12 units leave k_tiles)."""
     from hutoken_amd import _capi, data, synth
-    monkeypatch.setenv("HUTK_SPLIT_MERGE", "1")
+    monkeypatch.setenv("HUTK_SPLIT_MERGE", mode)
     if no_table:
         monkeypatch.setenv("HUTK_NO_WORD_TABLE", "1")
     vp, sp, kw = data.vocab_files(g["vocab"])
