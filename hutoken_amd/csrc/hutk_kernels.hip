@@ -2697,6 +2697,7 @@ __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs
     __shared__ uint32_t e_pos[GATHER_EXC_LDS];
     __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
     __shared__ int64_t e_tok[GATHER_EXC_LDS];
+    __shared__ uint16_t e_ws[GATHER_EXC_LDS];  // start of the word inside the tile
     const int tid = threadIdx.x;
     const uint32_t n_list = W.counters[1];
     for (uint32_t li = vblock; li < n_list; li += vgrid) {
@@ -2720,6 +2721,7 @@ __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs
         e_pos[e] = recs[e].wpos;
         e_cum[e + 1] = recs[e].tok_base < 0 ? 0u : recs[e].cnt;  // (a word that was too large has no ids)
         e_tok[e] = recs[e].tok_base;
+        e_ws[e] = (uint16_t)(recs[e].ws - tile * TILE_BYTES);
     }
     wave_sync();
     {   // running sum of the counts, 64 at a time (a tile of long-word text has hundreds of them)
@@ -2745,6 +2747,23 @@ __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs
         A.ids_out[base + k + e_cum[lo]] = sym_to_id(T, run_sym(k));
     }
     for (uint32_t e = tid; e < nexc; e += GATHER_THREADS) recs[e].out_pos = base + e_pos[e] + e_cum[e];
+    {   // out_offsets of the documents that start in this tile (d_doc_off leaves them to us: the ids of the exception
+        // words in front of a document are a prefix sum we hold in LDS, there they were a loop over the records)
+        const int64_t t0 = tile * TILE_BYTES;
+        const int64_t t_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
+        for (int64_t d = W.tile_first_doc[tile] + tid; d <= A.n_docs; d += GATHER_THREADS) {
+            const int64_t o = A.offsets[d];
+            if (o >= t_end) break;
+            if (o < t0) continue;
+            const uint32_t r = (uint32_t)(o - t0);
+            uint32_t lo = 0, hi = nexc;  // records with ws < o
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (e_ws[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            A.out_offsets[d] = base + W.doc_tile_pos[d] + e_cum[lo];
+        }
+    }
     // the ids of all exception words of the tile as one flat range: element k belongs to the word e with
     // e_cum[e] <= k < e_cum[e + 1] and lands at base + wpos(e) + k; lanes are independent, so the loads of a
     // whole stride are in flight together (one word after the other, each trip waited for its own loads)
@@ -2772,13 +2791,8 @@ __device__ __forceinline__ void d_doc_off(const BatchArgs& A, const Workspace& W
         return;
     }
     const int64_t tile = o / TILE_BYTES;
-    int64_t v = W.tile_base[tile] + W.doc_tile_pos[d];
-    const uint32_t nexc = W.tile_nexc[tile];
-    if (nexc) {
-        const ExcRec* recs = W.exc + W.tile_exc_first[tile];
-        for (uint32_t e = 0; e < nexc; e++)
-            if (recs[e].ws < o) v += recs[e].cnt;
-    }
+    const int64_t v = W.tile_base[tile] + W.doc_tile_pos[d];
+    if (W.tile_nexc[tile]) return;  // a tile with exception words: d_gather_exc writes its documents' offsets
     A.out_offsets[d] = v;
 }
 
