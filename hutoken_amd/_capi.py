@@ -22,6 +22,7 @@ EXPORTS = [
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
     "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_profile_raw", "hutk_debug_tile_bytes",
+    "hutk_debug_seam",
 ]
 
 _lib = None
@@ -116,6 +117,9 @@ def load(build_if_missing=True):
         L.hutk_ctx_add_device.argtypes = [vp, i32]
         L.hutk_ctx_device_count.restype = i32
         L.hutk_ctx_device_count.argtypes = [vp]
+    if hasattr(L, "hutk_debug_seam"):
+        L.hutk_debug_seam.restype = i32
+        L.hutk_debug_seam.argtypes = [vp, vp]
     L.hutk_debug_profile.restype = i32
     L.hutk_debug_profile.argtypes = [vp, i32]
     L.hutk_debug_tile_bytes.restype = i32
@@ -268,6 +272,13 @@ class Context:
         raise_for(load().hutk_table_stats(self._h, out.ctypes.data))
         keys = ["n_keys", "n_vocab_sym", "n_sym", "n_pairs", "pair_slots", "rank_is_sym", "ident_ids", "n_word_entries"]
         return dict(zip(keys, out.tolist()))
+
+    def seam_map(self):
+        """-> (uint32[256], in use): bit y - 0xE0 of entry x set = some merge can join input bytes x | y."""
+        import numpy as np
+        out = np.zeros(256, dtype=np.uint32)
+        on = load().hutk_debug_seam(self._h, out.ctypes.data)
+        return out, bool(on)
 
     def encode_packed(self, data, offsets, want_status=True):
         """Host numpy buffers in, host numpy buffers out.

@@ -75,7 +75,7 @@ struct hutk_ctx {
     // device tables
     DevBuf<uint64_t> d_pair, d_char;
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
-    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms;
+    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms, d_seam;
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<WordSlot> d_word_tab;
@@ -92,7 +92,7 @@ struct hutk_ctx {
     // workspace
     DevBuf<uint32_t> w_run;
     DevBuf<int32_t> w_exc_tok;
-    DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters, w_defer;
+    DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
     DevBuf<uint32_t> w_exc_quad, w_exc_wave;
@@ -196,10 +196,16 @@ int upload_tables(hutk_ctx* c) {
     {  // splitter automaton: transition table + byte classes, independent of the vocabulary
         std::vector<uint8_t> buf(dfa::TABLE_BYTES + 256);
         dfa::build(reinterpret_cast<uint16_t*>(buf.data()), buf.data() + dfa::TABLE_BYTES);
+        for (uint32_t x = 0; x < 256; x++)  // the seam map rides in the rows' padding (hutk_classify.h)
+            memcpy(buf.data() + dfa::seam_offset(x), &T.seam_hi[x], 4);
         HIP_TRY(c->d_split_dfa.reserve(buf.size()));
         HIP_TRY(hipMemcpy(c->d_split_dfa.p, buf.data(), buf.size(), hipMemcpyHostToDevice));
         D.split_dfa = reinterpret_cast<const uint4*>(c->d_split_dfa.p);
     }
+    HIP_TRY(c->d_seam.reserve(256));
+    HIP_TRY(hipMemcpy(c->d_seam.p, T.seam_hi, sizeof T.seam_hi, hipMemcpyHostToDevice));
+    D.seam_hi = c->d_seam.p;
+    D.seam_on = T.seam_on && !(getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ? 1 : 0;
     D.item_sym = c->d_item_sym.p;
     D.item_direct = c->d_item_direct.p;
     D.char_slots = c->d_char.p;
@@ -215,7 +221,6 @@ int upload_tables(hutk_ctx* c) {
     D.rank_is_sym = T.rank_is_sym;
     D.ident_ids = T.ident_ids;
     D.sym16 = T.sym16;
-    D.split_merge = getenv("HUTK_SPLIT_MERGE") ? atoi(getenv("HUTK_SPLIT_MERGE")) : 0;  // 0 none, 1 all, 2 / 3: words over 16 / 12 units
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
     D.word_tab = nullptr;
     D.word_mask = 0;
@@ -309,7 +314,6 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     HIP_TRY(c->w_counters.reserve(8));
     HIP_TRY(c->w_err.reserve(1));
-    if (tiles_defer(c->dt)) HIP_TRY(c->w_defer.reserve((size_t)n_tiles * DEFER_WORDS + 64));
     const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_quad.reserve((size_t)cap_exc));
@@ -325,7 +329,6 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_exc_first = u + 3 * n_tiles;
     W.tile_nexc = u + 4 * n_tiles;
     W.exc_tiles = u + 5 * n_tiles;
-    W.tile_ndefer = u + 6 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
     W.scan_state = reinterpret_cast<unsigned long long*>(c->w_tile_i64.p + 2 * n_tiles + 2);
@@ -335,7 +338,6 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.exc_quad = c->w_exc_quad.p;
     W.exc_wave = c->w_exc_wave.p;
     W.counters = c->w_counters.p;
-    W.defer_mask = c->w_defer.p;
     W.cap_exc = cap_exc;
     W.pad_per_doc = (int32_t)pad;
     W.prof = nullptr;
@@ -356,11 +358,11 @@ void destroy(hutk_ctx* c) {
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
-        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
-        c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release(); c->w_defer.release();
+        c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
         c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
         c->dw_state.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
@@ -570,6 +572,11 @@ int hutk_uses_merges(const hutk_ctx* ctx) { return ctx && ctx->tab.id_path ? 1 :
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs : 0; }
 int hutk_device_ordinal(const hutk_ctx* ctx) { return ctx ? ctx->device : -1; }
 int64_t hutk_debug_pairs_second(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs_second : 0; }
+int hutk_debug_seam(const hutk_ctx* ctx, uint32_t* out256) {
+    if (!ctx || !out256) return set_err(HUTK_E_ARG, "bad argument");
+    memcpy(out256, ctx->tab.seam_hi, sizeof ctx->tab.seam_hi);
+    return ctx->tab.seam_on && !(getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ? 1 : 0;
+}
 void hutk_set_timing(hutk_ctx* ctx, int enabled) {
     if (ctx) ctx->timing = enabled != 0;
 }
@@ -690,7 +697,6 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     launch_tiles(c->dt, A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
-    launch_merge(c->dt, A, W, s);  // (before the exception kernels: it sets a tile's id count, they add to it)
     if (small_tail(A)) {
         launch_tail_small(c->dt, A, W, s);
     } else {

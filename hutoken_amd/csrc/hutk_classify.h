@@ -315,6 +315,15 @@ constexpr int ROW_BYTES = 128;                     // one row per state: 2 * N_C
 constexpr int DOC_COL_BYTES = 2 * N_CLS;           // the columns for "a document starts at this byte"
 constexpr int TABLE_BYTES = N_STATES * ROW_BYTES;
 static_assert(2 * DOC_COL_BYTES <= ROW_BYTES, "row holds both column sets");
+// The 36 bytes a row leaves free hold the seam map (hutk_internal.h, Tables::seam_hi; 256 dwords) of the context, nine
+// entries per row, so that k_tiles finds it in LDS beside the automaton: entry x at seam_offset(x).
+constexpr int ROW_FREE = 2 * DOC_COL_BYTES, SEAM_PER_ROW = (ROW_BYTES - ROW_FREE) / 4;
+static_assert(ROW_FREE % 4 == 0 && SEAM_PER_ROW * N_STATES >= 256, "the seam map fits the rows' padding");
+HUTK_CLS_HD uint32_t seam_offset(uint32_t x) {  // byte offset into the table of entry x (x < 256)
+    const uint32_t r = (x * 57u) >> 9;          // x / 9
+    return r * (uint32_t)ROW_BYTES + (uint32_t)ROW_FREE + 4u * (x - 9u * r);
+}
+static_assert(SEAM_PER_ROW == 9, "seam_offset divides by nine");
 
 inline int byte_class(uint32_t b) {
     if (b < 0x80u) {

@@ -23,10 +23,6 @@ constexpr int LANE_MAX_BYTES = 63;   // and its byte length (its end must be wit
 // prefix units / prefix-alone ids granted to document-first words (beyond that budget: exception path)
 constexpr int RUN_EXTRA = 64;
 constexpr int RUN_STRIDE = TILE_BYTES + 64 + RUN_EXTRA;
-// k_merge: a word that waits for it owns a stretch of its tile's run, one slot per unit; bit p of the tile's
-// DEFER_WORDS-dword bitmap marks the stretch that begins at slot p, unused slots of a stretch end up RUN_DEAD
-constexpr int DEFER_WORDS = (RUN_STRIDE + 31) / 32;
-constexpr uint32_t RUN_DEAD = 0xFFFEu;  // (16-bit symbols stay below 0xFFF0; 0xFFFF is the unit that is no symbol)
 constexpr int EXC_LDS_UNITS = 1024;  // exception words up to this many units merge in LDS
 
 // per-position codes produced by the classifier (parser.c:24-183 restated as a
@@ -62,10 +58,6 @@ struct DevTables {
     // [b1 << 8 | b2], stored as uint16 when sym16 else uint32 (SYM_NONE when unranked)
     const void* bytepair;
     int32_t sym16;  // every symbol < 0xFFF0: LDS arrays hold 16-bit symbols
-    // 1: k_tiles leaves the merge loop to k_merge + k_compact (byte-encoder mode, 16-bit symbols, rank == symbol order
-    // only).  Slower on the benchmark's text (two kernels bound by table gathers one after the other, 146 against 175
-    // GB/s), faster where every word merges (81 against 68 GB/s on 17-31-letter random words): off unless asked for
-    int32_t split_merge;
     // whole-word table: raw word bytes of 2..14 (12) bytes, zero padded -> symbol of the one token the word encodes to.
     // Two-choice cuckoo, 16-byte slots (WordSlot), an empty slot is all zero (a key's first bytes never are); slot 1 = hash & mask,
     // slot 2 = word_slot2(hash, mask) (hutk_internal.h).  word_mask == 0: no table.
@@ -76,6 +68,10 @@ struct DevTables {
     // the word splitter as an automaton (hutk_classify.h, namespace dfa): dfa::TABLE_BYTES of transition table, then
     // the 256-byte byte-class table; the same for every vocabulary, staged in LDS by k_tiles
     const uint4* split_dfa;
+    // seam map (Tables::seam_hi): bit (y - 0xE0) of seam_hi[x] clear = no token can span the input bytes x | y, so a word
+    // of its own starts at y (k_tiles, exc_word_end).  seam_on == 0: never split (regex path, HUTK_NO_SEAM=1)
+    const uint32_t* seam_hi;
+    int32_t seam_on;
 };
 
 // one word the tile kernel hands to the exception kernel
@@ -110,8 +106,6 @@ struct Workspace {
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in d_exc (count: counters[5])
     uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
-    uint32_t* tile_ndefer;     // [n_tiles] words of the tile that k_merge encodes
-    uint32_t* defer_mask;      // [n_tiles * DEFER_WORDS] stretches of the run that k_merge fills in (see DEFER_WORDS)
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
     long long* prof;           // diagnostic: [n_tiles][10] clock64 stamps of k_tiles, or null
@@ -166,8 +160,6 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s);
 void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s);  // v[i] += *base; *base = v[n-1]
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
-void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);  // no-op unless tiles_defer(t)
-bool tiles_defer(const DevTables& t);  // k_tiles leaves the merge loop to k_merge for this context
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
 int64_t scan_blocks(int64_t n_tiles);

@@ -161,6 +161,13 @@ struct Tables {
     std::vector<uint32_t> cand_off;    // [n+1]
     std::vector<uint32_t> cand_sym;    // [n]
 
+    // Seam map: bit (y - 0xE0) of seam_hi[x] = some merge can join a token that ends with input byte x to one that
+    // begins with input byte y (y >= 0xE0: the lead bytes of three- and four-byte characters).  A clear bit is a place
+    // where no token can ever span x | y: the word's encoding is the concatenation of the encodings of its two sides, and
+    // the tile kernel starts a word of its own at y (hutk_loader.cpp, seam_from_pairs).
+    uint32_t seam_hi[256] = {0};
+    bool seam_on = false;
+
     bool is_byte_encoder = false;
     bool has_prefix = false;
     std::vector<uint32_t> prefix_syms;        // units of the prefix when it is prepended to a word

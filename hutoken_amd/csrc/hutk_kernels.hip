@@ -43,6 +43,7 @@
 
 #include "hutk_classify.h"
 #include "hutk_device.h"
+#include "hutk_lab.h"
 
 namespace hutk {
 
@@ -265,29 +266,9 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 // word that starts in the tile may end).  Lane l owns positions 16l .. 16l+15.
 // Workgroup barriers only around the pooled merge phase.
 //
-// Build switches (defaults are what ships; the others exist for A/B runs with tools/ab.py and for the
-// measurements quoted in DESIGN.md section 5):
-//   HUTK_TILE_WAVES   tiles per workgroup (4; 8 and 16 measured no faster)
-//   HUTK_WAVES_EU     resident wavefronts per SIMD the byte-mode kernel is compiled for (8 = 64 VGPRs)
-//   HUTK_CHAR_EU      the same outside byte-encoder mode (6: LDS-limited)
-//   HUTK_LDS_TIGHT    1: pool and merge array sized so that 8 workgroups fit a CU's LDS; 0: roomier (7)
-//   HUTK_SPLIT_SWAR   1: classify with the SWAR mask algebra instead of the automaton
-//   HUTK_FAST_MERGE   0: the general merge loop also where the short form (packed keys) applies
-//   HUTK_STAGE_RUN    1: a tile's symbols go to HBM through LDS as 16-byte stores instead of lane by lane (measured: -1 %)
-//   HUTK_ABLATE_MERGE 1: MEASUREMENT ONLY, no word is merged (wrong ids): instruction count of the other phases
-//   HUTK_SCAN_RAW     1 (default): the rescan takes "no candidate left" as index -1 (v_ffbl's answer for 0), whose key is
-//                     all ones: 25 instead of 37 VALU instructions per four candidates
-//   HUTK_PUBLISH_LATE 1 (default): a word's surviving units are published after the trip loop, not in the trip it ends in
-//   HUTK_LANE_RETRY   1 (default): a pair lookup that must go on in its second bucket is repeated by ITS lane in the next
-//                     trip instead of making the whole wavefront wait for a second round trip inside the trip.
-//                     The three together, 200 k documents on one box: C3 164.8 -> 169.1, C2 185.0 -> 188.8 GB/s; random
-//                     17-31-letter words (every lane busy in every trip) 66.3 -> 60.8.  Each alone: within +-1 %.
-//   HUTK_TRIP_PRIO     n: s_setprio(n) around the merge trips (+-0 %)
-//   HUTK_WORD_SECOND_LATE 1: the whole-word table's second slot only for lanes that missed in the first (+-0 %)
-//   HUTK_NT_STREAM    1: non-temporal loads of the input and stores of the run (-2.5 %)
-//   HUTK_PERTURB_VALU / _SLEEP / _MEM: MEASUREMENT ONLY, extra VALU instructions / idle cycles / 16-byte gathers per
-//                     tile: what the kernel's time responds to
-//   HUTK_MERGE_STAMPS 1: MEASUREMENT ONLY, the clock stamps are spent inside the merge phase
+// Build switches: HUTK_TILE_WAVES tiles per workgroup (4; 2, 6, 8 and 16 measured no faster), HUTK_WAVES_EU resident
+// wavefronts per SIMD the byte-mode kernel is compiled for (8 = 64 VGPRs), HUTK_CHAR_EU the same outside byte-encoder
+// mode (6: LDS-limited).  Measurement-only switches: hutk_lab.h.  What was tried and dropped: DESIGN.md section 5.
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
 #ifndef HUTK_CHAR_EU
@@ -302,51 +283,6 @@ constexpr int N_PHASE = 10;
 constexpr int TILE_WAVES = HUTK_TILE_WAVES;  // tiles (= wavefronts) per workgroup of k_tiles
 constexpr int NPOS = TILE_BYTES + HALO;  // 1024 classified positions, 16 per lane
 static_assert(NPOS == 64 * 16, "16 positions per lane");
-
-#ifndef HUTK_PERTURB_VALU
-#define HUTK_PERTURB_VALU 0
-#endif
-#ifndef HUTK_FAST_TRIPS_ANY_MODE
-#define HUTK_FAST_TRIPS_ANY_MODE 1  // the short form's trips outside byte-encoder mode too (rank == symbol order, 16-bit symbols)
-#endif
-#ifndef HUTK_TRIP_PRIO
-#define HUTK_TRIP_PRIO 0
-#endif
-#ifndef HUTK_WORD_SECOND_LATE
-#define HUTK_WORD_SECOND_LATE 0
-#endif
-#ifndef HUTK_NT_STREAM
-#define HUTK_NT_STREAM 0
-#endif
-#ifndef HUTK_PERTURB_MEM
-#define HUTK_PERTURB_MEM 0
-#endif
-#ifndef HUTK_PERTURB_SLEEP
-#define HUTK_PERTURB_SLEEP 0
-#endif
-#ifndef HUTK_LANE_RETRY
-#define HUTK_LANE_RETRY 1
-#endif
-#ifndef HUTK_SCAN_RAW
-#define HUTK_SCAN_RAW 1
-#endif
-#ifndef HUTK_PUBLISH_LATE
-#define HUTK_PUBLISH_LATE 1
-#endif
-#ifndef HUTK_MERGE_STAMPS
-#define HUTK_MERGE_STAMPS 0  // 1: MEASUREMENT ONLY, the ten clock stamps are spent inside the merge phase (tools/profile_phases.py)
-#endif
-#define HUTK_STAMP_AT(k)                                                       \
-    do {                                                                       \
-        if (W.prof && lane == 0) W.prof[tile * N_PHASE + (k)] = clock64();     \
-    } while (0)
-#if HUTK_MERGE_STAMPS
-#define HUTK_STAMP(k) do {} while (0)
-#define HUTK_MSTAMP(k) do { if (tile_ok) HUTK_STAMP_AT(k); } while (0)
-#else
-#define HUTK_STAMP(k) HUTK_STAMP_AT(k)
-#define HUTK_MSTAMP(k) do {} while (0)
-#endif
 
 // byte k (0..31) of a 32-byte register window
 struct Win { uint64_t a, b, c, d; };
@@ -394,56 +330,38 @@ struct TileLds {
     uint32_t arena_used, extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
 };
 
-// KEEP: the merge loop runs in this kernel for words of up to KEEP units (pooled per workgroup); longer ones are left to
-// k_merge.  LANE_MAX_UNITS: everything here (the default); 1: everything in k_merge; in between: only the long tail,
-// which is what a workgroup's closing barrier otherwise waits for.
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, int KEEP = LANE_MAX_UNITS>
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
-#ifndef HUTK_LDS_TIGHT
-#define HUTK_LDS_TIGHT 1
-#endif
-    constexpr int POOL_CAP = (HUTK_LDS_TIGHT ? 64 : 128) * WAVES;
-    [[maybe_unused]] constexpr int POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
+    constexpr int POOL_CAP = 64 * WAVES;
+    constexpr int POOL_LONG_CAP = POOL_CAP * 3 / 8, POOL_LONG = 8;
     static_assert(WAVES <= 32, "pool entries keep the tile-in-workgroup index in 6 bits");
-#ifndef HUTK_FAST_MERGE
-#define HUTK_FAST_MERGE 1
-#endif
-#ifndef HUTK_STAGE_RUN
-#define HUTK_STAGE_RUN 0
-#endif
-    // the merge loop's short form: byte-encoder mode, 16-bit symbols, rank == symbol order (GPT-2-shaped files)
-    constexpr bool FAST = HUTK_FAST_MERGE && BYTE_MODE && RANK_IS_SYM && sizeof(SymT) == 2;
-    // ... whose trips (not its set-up, which reads the (byte, next byte) table) serve the other mode as well
-    constexpr bool FAST_TRIPS = HUTK_FAST_MERGE && HUTK_FAST_TRIPS_ANY_MODE ? (RANK_IS_SYM && sizeof(SymT) == 2) : FAST;
-    // ... and then the merge loop is not run here at all: a word that needs it RESERVES one slot per unit in the
-    // tile's run, leaves its start and unit count in the first two, and k_merge fills the slots in (see there)
-    constexpr bool DEFER = FAST && KEEP < LANE_MAX_UNITS;
-    static_assert(FAST || KEEP == LANE_MAX_UNITS, "k_merge is the short form of the merge loop");
+    // the merge loop's short form: 16-bit symbols, rank == symbol order (GPT-2-shaped files, and the id-keyed path)
+    constexpr bool FAST_TRIPS = RANK_IS_SYM && sizeof(SymT) == 2;
     __shared__ Tile L[WAVES];
-    __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of m handed out
+    __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of the arena handed out
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
     // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
     // m[its offset + i]; a word gets its stretch of m when it enters the pool (a position-indexed array per tile
-    // would be four times the size, and LDS is what limits the resident wavefronts).  The merge phase begins
-    // behind a workgroup barrier that every wavefront passes after its classification, so until then the same
-    // LDS holds the splitter automaton (hutk_classify.h): transition table, then byte classes.
-    constexpr int M_ARENA = HUTK_LDS_TIGHT ? 352 * WAVES + 192 : 2048;
+    // would be four times the size, and LDS is what limits the resident wavefronts).
+    // The merge phase begins behind a workgroup barrier that every wavefront passes after its classification, so until
+    // then the same LDS holds the splitter automaton (hutk_classify.h): transition table, then byte classes.
+    constexpr int M_ARENA = 352 * WAVES + 192;
     struct MergeLds {
-        SymT m[M_ARENA];
+        __attribute__((aligned(16))) SymT m[M_ARENA];
         uint32_t pool[POOL_CAP];
     };
     struct SplitLds {
         uint8_t dfa[dfa::TABLE_BYTES];
         uint8_t lut[256];
     };
-    static_assert(M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
     __shared__ __attribute__((aligned(16))) union {
         MergeLds g;
         SplitLds c;
     } s_m;
+    static_assert(M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
     uint32_t* const pool = s_m.g.pool;
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -526,12 +444,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         for (int c = lane; c < WINDOW / 16; c += 64) {
             const int64_t p = gw + 16 * c;
             if (p >= 0 && p + 16 <= A.n_bytes) {
-#if HUTK_NT_STREAM
-                typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-                *reinterpret_cast<v4u*>(sb + 16 * c) = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(A.bytes + p));
-#else
                 *reinterpret_cast<uint4*>(sb + 16 * c) = *reinterpret_cast<const uint4*>(A.bytes + p);
-#endif
             } else {
                 for (int k = 0; k < 16; k++) {
                     const int64_t q = p + k;
@@ -576,18 +489,38 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 flags = reinterpret_cast<const uint16_t*>(A.word_bits)[(t0 >> 4) + lane];
                 exotic = false;
             } else {
-#if HUTK_SPLIT_SWAR
-                flags = classify16(dw, dbits, &exotic);           // byte-parallel mask algebra (hutk_classify.h)
-#else
                 flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.c.dfa), s_m.c.lut,
                                        &exotic);                   // the automaton: one LDS lookup per byte
-#endif
             }
             if (exotic) {  // overlong encodings: per-position decode
                 Win8 w8;
     #pragma unroll
                 for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
                 flags = classify16_exact_cold(w8, dbits);
+            }
+            if (T.seam_on && !A.word_bits) {
+                // Seams (hutk_internal.h, Tables::seam_hi): where no merge can join the input byte x to the lead byte y of the
+                // three- or four-byte character behind it, the word's encoding is the concatenation of the encodings of
+                // its two sides (core.c:66-209 merges only what the pair table holds), so y starts a word of its own:
+                // runs of CJK characters become table words instead of the merge loop's longest ones.
+                const uint64_t K8 = 0x8080808080808080ull;
+                uint64_t m0 = w.b & (w.b << 1) & (w.b << 2) & K8;  // bytes >= 0xE0 among my positions 0..7
+                uint64_t m1 = w.c & (w.c << 1) & (w.c << 2) & K8;  // ... 8..15
+                if (m0 | m1) {
+                    const uint64_t p0 = (w.b << 8) | (w.a >> 56), p1 = (w.c << 8) | (w.b >> 56);  // the byte in front of each
+                    for (; m0; m0 &= m0 - 1) {
+                        const int sh = __builtin_ctzll(m0) - 7;
+                        const uint32_t y = (uint32_t)(w.b >> sh) & 0xFFu, x = (uint32_t)(p0 >> sh) & 0xFFu;
+                        const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_m.c.dfa + dfa::seam_offset(x));
+                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (sh >> 3);
+                    }
+                    for (; m1; m1 &= m1 - 1) {
+                        const int sh = __builtin_ctzll(m1) - 7;
+                        const uint32_t y = (uint32_t)(w.c >> sh) & 0xFFu, x = (uint32_t)(p1 >> sh) & 0xFFu;
+                        const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_m.c.dfa + dfa::seam_offset(x));
+                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (8 + (sh >> 3));
+                    }
+                }
             }
         }
         {  // a 0x00 byte inside the data is an error (the reference's strings end there): any zero among my 16 bytes?
@@ -701,9 +634,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 uint32_t isym = 0;
                 if (T.word_mask) {  // uniform
                     s1 = reinterpret_cast<const uint4*>(T.word_tab)[h1];
-#if !HUTK_WORD_SECOND_LATE
                     s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
-#endif
                 }
                 if (!BYTE_MODE && T.wordl_mask && __any(probe_long)) {  // (uniform; many rounds have no such word)
                     if (probe_long) l1 = T.wordl_tab[wh & T.wordl_mask];  // ONE choice: see build_word_table
@@ -726,16 +657,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     // (the probed word's bytes beyond WORD_KEY are zero: k3 has nothing in the symbol's place)
                     constexpr int KSH = sizeof(SymT) == 2 ? 16 : 32;  // bits of k[3] that are symbol, not key
                     const uint32_t d1 = KSH == 32 ? 0u : (s1.w ^ k3) << (KSH & 31);
-#if !HUTK_WORD_SECOND_LATE
                     const uint32_t d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
-#endif
                     const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2) | d1) == 0;
-#if HUTK_WORD_SECOND_LATE
-                    // the second slot only for the lanes whose word is not in its first: a second round trip for the round,
-                    // but a third fewer gather accesses (the builder gives a word its first slot whenever that is free)
-                    if (!hit1) s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
-                    const uint32_t d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
-#endif
                     const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2) | d2) == 0;
                     done = hit1 || hit2;
                     const uint32_t sw = hit1 ? s1.w : s2.w;
@@ -814,12 +737,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 
     // ---- 6. merge: the workgroup POOLS the merge-loop words of its WAVES tiles ------------------------
     // One lane per word, one merge step per trip, and a wavefront runs as many trips as its longest word
-    // needs.  A tile has ~20 such words, a few of them long: merged by its own wavefront, 2/3 of the lanes
-    // would idle and every tile would pay the long trip count.  Pooled, the words fill whole wavefronts, long
-    // ones first, and the short rest finishes in a few trips.  The instruction stream is what bounds this
-    // kernel, so that is worth three workgroup barriers.
+    // needs.  A tile has ~10 such words, a few of them long: merged by its own wavefront, most lanes would idle and
+    // every tile would run the long trip count (measured, -16 %: the kernel is short of instruction issue slots, not
+    // only of latency).  Pooled, the words fill one wavefront, long ones first.
     //   pool[0 .. n_long)              words with more than POOL_LONG units
-    //   pool[POOL_CAP-1 downto ...]    the others; an entry is offset in m << 16 | tile-in-workgroup << 10 | word start
+    //   pool[POOL_CAP-1 downto ...]    the others; an entry is arena offset << 16 | tile-in-workgroup << 10 | word start
     // Words that do not fit stay in their tile's mergem and go into the next epoch (rare).
 #if HUTK_ABLATE_MERGE
     if (tile_ok) reinterpret_cast<uint16_t*>(mergem)[lane] = 0;  // MEASUREMENT ONLY: no word is merged (wrong ids)
@@ -828,28 +750,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     for (int i = 0; i < HUTK_PERTURB_SLEEP; i++) __builtin_amdgcn_s_sleep(127);  // MEASUREMENT ONLY: ~8 k cycles each, no VALU
 #endif
     [[maybe_unused]] bool first_epoch = true;
-    if constexpr (KEEP > 1)
     for (;;) {
 #if HUTK_MERGE_STAMPS
         if (first_epoch && tile_ok && W.prof && lane == 0)  // the SIMD this wavefront runs on (HW_ID bits 5:4) in the stamp's low bits
             W.prof[tile * N_PHASE + 0] = (clock64() & ~3ll) | (long long)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 #endif
-        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = (FAST_TRIPS && HUTK_SCAN_RAW) ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
-        __syncthreads();
+        if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = FAST_TRIPS ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
+        __syncthreads();  // (also: every wavefront is done with the automaton, whose LDS the merge arrays reuse)
         if (first_epoch) HUTK_MSTAMP(1);
         uint32_t pending = 0;
         if (tile_ok) {
             pending = reinterpret_cast<const uint16_t*>(mergem)[lane];
-            uint32_t later = 0;  // words of more than KEEP units: they stay marked in mergem for the epilogue and k_merge
             for (uint32_t m = pending; m; m &= m - 1) {
                 const int j = __builtin_ctz(m);
                 const int ws = 16 * lane + j;
                 const int n = word_units(me, ws);
-                if (DEFER && n > KEEP) {
-                    later |= 1u << j;
-                    pending &= ~(1u << j);
-                    continue;
-                }
                 const bool is_long = n > POOL_LONG;
                 const uint32_t moff = atomicAdd(&pool_cnt[2], (uint32_t)n);
                 if (moff + n > (uint32_t)M_ARENA) continue;  // no room in m this epoch
@@ -859,7 +774,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     pending &= ~(1u << j);
                 }
             }
-            reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)(pending | later);
+            reinterpret_cast<uint16_t*>(mergem)[lane] = (uint16_t)pending;
         }
         if (first_epoch) HUTK_MSTAMP(2);
         __syncthreads();
@@ -898,13 +813,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         // fewer than four left: the index of "no bit" is -1, whose key is all ones whatever m[offset - 1]
                         // holds (a word's stretch never starts at m[0], so that is a slot of this array)
                         const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
-#if HUTK_SCAN_RAW
                         const int i0 = ffbl_raw(c), i1 = ffbl_raw(c1), i2 = ffbl_raw(c2), i3 = ffbl_raw(c3);
-#else
-                        const int i0 = __builtin_ctz(c);
-                        const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
-                                  i3 = c3 ? __builtin_ctz(c3) : i0;
-#endif
                         const uint32_t k0 = ((uint32_t)Mw[i0] << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw[i1] << 5) | (uint32_t)i1,
                                        k2 = ((uint32_t)Mw[i2] << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw[i3] << 5) | (uint32_t)i3;
                         b = min(min(b, k0), min(min(k1, k2), k3));
@@ -987,12 +896,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #if HUTK_MERGE_STAMPS
                 long long ts_issue = 0, ts_scan = 0, ts_resolve = 0, ts_trips = 0;
 #endif
-#if HUTK_TRIP_PRIO
-                // The trips are one dependent chain per wavefront (~75 VALU instructions and a table round trip each) and the
-                // rest of the workgroup waits for the longest: their instructions go ahead of the other wavefronts' on the SIMD
-                __builtin_amdgcn_s_setprio(HUTK_TRIP_PRIO);
-#endif
-#if HUTK_LANE_RETRY
                 // A lookup that must go on in the pair's SECOND bucket (a filter bit of the first one says so; under 1 % of
                 // the lookups) is not followed up inside the trip: with 64 lanes and two lookups each, nearly every trip
                 // had some lane in that case, and every lane paid its extra round trip(s).  The lane keeps its trip's state
@@ -1005,14 +908,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     const long long tt0 = clock64();
                     long long tt1 = tt0, tt2 = tt0;
 #endif
-#if HUTK_PUBLISH_LATE
                     have = have && (best != NOKEY || rsA != 0);
-#else
-                    if (have && best == NOKEY && rsA == 0) {  // done: publish the surviving units (unit 0 is in livem already)
-                        publish();
-                        have = false;
-                    }
-#endif
                     if (!__any(have)) break;
                     if (have) {
                         int p, p0;
@@ -1091,72 +987,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     }
 #endif
                 }
-#else
-                for (;;) {
-#if HUTK_MERGE_STAMPS
-                    const long long tt0 = clock64();
-                    long long tt1 = tt0, tt2 = tt0;
-#endif
-#if HUTK_PUBLISH_LATE
-                    have = have && best != NOKEY;
-#else
-                    if (have && best == NOKEY) {  // done: publish the surviving units (unit 0 is in livem already)
-                        publish();
-                        have = false;
-                    }
-#endif
-                    if (!__any(have)) break;
-                    if (have) {
-                        const int p = (int)(best & 31u);
-                        const uint32_t merged = best >> 5;
-                        const uint32_t above = live & ~((2u << p) - 1u);  // not empty: bit p of cand was set
-                        const int q = __builtin_ctz(above);               // the unit the merge consumes
-                        Sw[p] = (SymT)merged;
-                        live &= ~(1u << q);
-                        const uint32_t right = above & (above - 1u);    // live units after q
-                        const uint32_t left = live & ((1u << p) - 1u);  // live units before p: none iff p == 0
-                        const int q2 = __builtin_ctz(right | 0x80000000u);
-                        const int p0 = 31 - __builtin_clz(left | 1u);   // == p when there is none
-                        const uint32_t sr = Sw[q2], sl = Sw[p0];         // (read and looked up even when absent)
-                        const PairProbe s1 = pair_issue(T, merged, sr);
-                        const PairProbe s2 = pair_issue(T, sl, merged);
-#if HUTK_MERGE_STAMPS
-                        tt1 = clock64();
-#endif
-                        cand &= ~((1u << q) | (1u << p) | (1u << p0));
-                        best = scan_key(cand);
-#if HUTK_MERGE_STAMPS
-                        tt2 = clock64();
-#endif
-                        uint32_t mr = pair_resolve(T, s1, merged, sr), ml = pair_resolve(T, s2, sl, merged);
-                        mr = right ? mr : SYM_NONE;
-                        ml = left ? ml : SYM_NONE;
-                        Mw[p0] = (SymT)ml;  // first: without a left neighbour p0 == p
-                        Mw[p] = (SymT)mr;
-                        const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
-                        cand |= ((hr ? 1u : 0u) << p) | ((hl ? 1u : 0u) << p0);
-                        const uint32_t kr = hr ? ((mr << 5) | (uint32_t)p) : NOKEY;
-                        const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
-                        best = min(best, min(kr, kl));
-                    }
-#if HUTK_MERGE_STAMPS
-                    {   // lane 0's view of the trip (it holds the pool's longest word)
-                        const long long tt3 = clock64();
-                        ts_issue += tt1 - tt0; ts_scan += tt2 - tt1; ts_resolve += tt3 - tt2; ts_trips++;
-                    }
-#endif
-                }
-#endif
-#if HUTK_TRIP_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #if HUTK_MERGE_STAMPS
                 if (first_epoch && base == 64u * wv && tile_ok && W.prof && lane == 0) {
                     W.prof[tile * N_PHASE + 7] = ts_issue; W.prof[tile * N_PHASE + 8] = ts_scan;
                     W.prof[tile * N_PHASE + 9] = ts_resolve | (ts_trips << 40);
                 }
 #endif
-                if (HUTK_PUBLISH_LATE && mine) {  // publish the surviving units (unit 0 is in livem already)
+                if (mine) {  // publish the surviving units (unit 0 is in livem already)
                     publish();
                 }
                 wave_sync();
@@ -1324,17 +1161,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
         return x;
     };
-    // DEFER: a word that waits for k_merge reserves one slot per unit (its start bit counts the first)
-    const uint32_t defer16 = DEFER ? reinterpret_cast<const uint16_t*>(mergem)[lane] : 0u;
-    auto defer_extra = [&](int lr, uint32_t starts) -> uint32_t {
-        uint32_t x = 0;
-        if (DEFER)
-            for (uint32_t m = starts; m; m &= m - 1) x += (uint32_t)word_units(me, 16 * lr + __builtin_ctz(m)) - 1u;
-        return x;
-    };
-    // one scan for three counts: ids (bits 0-10, at most RUN_STRIDE), exception words (11-20), words left to k_merge (21-30)
-    uint32_t mine = (uint32_t)__popc(live16) + defer_extra(lane, defer16) + extra_ids(lane, own) +
-                    ((uint32_t)__popc(exc16) << 11) + ((uint32_t)__popc(defer16) << 21);
+    // one scan for two counts: ids (bits 0-10, at most RUN_STRIDE), exception words (11-20)
+    uint32_t mine = (uint32_t)__popc(live16) + extra_ids(lane, own) + ((uint32_t)__popc(exc16) << 11);
     uint32_t total;
     uint32_t run = wave_excl_scan(mine, lane, &total);
     lanepref[lane] = (uint16_t)(run & 0x7FFu);
@@ -1356,17 +1184,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         W.tile_run_start[tile] = 0;
         W.tile_exc_first[tile] = exc_first;
         W.tile_nexc[tile] = n_exc;
-        if (DEFER) W.tile_ndefer[tile] = total >> 21;
     }
     exc_first = __shfl(exc_first, 0, 64);
     HUTK_STAMP(6);
-    // symbols in the width the LDS arrays use (k_gather widens them and turns them into ids).  Byte-encoder mode:
-    // the run is collected in LDS (the tile's byte window is no longer needed) and leaves as whole 16-byte stores;
-    // a lane's ids are few and scattered 2-byte global stores cost an address cycle each.  A tile with more ids
-    // than the window holds, and the other mode (whose epilogue still reads the bytes), store directly.
+    // symbols in the width the LDS arrays use (k_finish widens them and turns them into ids), stored lane by lane
+    // (collected in LDS first and stored as 16-byte vectors: measured no faster)
     SymT* run_out = reinterpret_cast<SymT*>(W.run) + tile * RUN_STRIDE;
-    constexpr uint32_t STAGE_CAP = (uint32_t)(sizeof(me.sb) / sizeof(SymT));
-    const bool staged = BYTE_MODE && HUTK_STAGE_RUN && n_dense <= STAGE_CAP;  // the same for the whole wavefront
     auto emit_run = [&](SymT* dst) {
         uint32_t pos = run & 0x7FFu, eidx = (run >> 11) & 0x3FFu;
         uint32_t ev = live16 | exc16;
@@ -1405,39 +1228,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const uint32_t na = alone_ids(ws);
                 for (uint32_t i = 0; i < na; i++) dst[pos++] = Sym<SymT>::narrow(T.prefix_alone_syms[i]);
             }
-            if (DEFER && ((defer16 >> j) & 1u)) {
-                // reserved stretch: {word start, unit count} now, the word's symbols (then RUN_DEAD) from k_merge
-                const uint32_t n = (uint32_t)word_units(me, ws);
-                dst[pos] = (SymT)ws;
-                dst[pos + 1] = (SymT)n;
-                atomicOr(&docm[pos >> 5], 1u << (pos & 31));  // (docm is free in this mode: bitmap of the stretches' first slots)
-                pos += n;
-                continue;
-            }
-#if HUTK_NT_STREAM
-            if ((live16 >> j) & 1u) __builtin_nontemporal_store(S[ws], &dst[pos++]);
-#else
             if ((live16 >> j) & 1u) dst[pos++] = S[ws];  // stores only: nothing here waits
-#endif
         }
     };
-    if (DEFER) {
-        if (lane < DEFER_WORDS) docm[lane] = 0;
-        wave_sync();
-    }
-    if (staged) {
-        emit_run(reinterpret_cast<SymT*>(sb));
-        wave_sync();
-        const uint32_t nvec = (n_dense * (uint32_t)sizeof(SymT) + 15u) / 16u;
-        for (uint32_t v = lane; v < nvec; v += 64)
-            reinterpret_cast<uint4*>(run_out)[v] = reinterpret_cast<const uint4*>(sb)[v];
-    } else {
-        emit_run(run_out);
-    }
-    if (DEFER) {
-        wave_sync();
-        if (lane < DEFER_WORDS) W.defer_mask[tile * DEFER_WORDS + lane] = docm[lane];
-    }
+    emit_run(run_out);
     wave_sync();
     HUTK_STAMP(7);
 
@@ -1452,291 +1246,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         uint32_t before = lanepref[lr];
         before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(livem)[lr] & below);
         before += extra_ids(lr, wmask16[lr] & below);
-        before += defer_extra(lr, reinterpret_cast<const uint16_t*>(mergem)[lr] & below);
         W.doc_tile_pos[d] = before;
     }
     HUTK_STAMP(8);
     HUTK_STAMP(9);
-}
-
-// ------------------------------------------------------------------------
-// k_merge: THE MERGE LOOP (src/core.c:66-209; rule "leftmost pair of minimal rank", src/queue.c:152-199) for the words
-// k_tiles left to it (byte-encoder mode, 16-bit symbols, rank == symbol order).  Inside k_tiles the loop made every
-// wavefront of a workgroup wait for the workgroup's longest word -- two thirds of that kernel's time.  Here a workgroup
-// takes the words of MG_TILES consecutive tiles, SORTS them by unit count in LDS (counting sort) and merges them 64 at a
-// time, one word per lane, so that the lanes of a chunk need about the same number of trips; no tile state is held
-// while it runs, so many workgroups are resident and their memory round trips overlap.
-//   1. the tiles' stretch bitmaps -> a list of words {tile, slot, start, units}, sorted by units (longest first)
-//   2. per chunk of 64: symbols and initial pair results of a word from its bytes (HBM) through the (byte, next byte)
-//      table; then one merge per trip with packed keys (merged symbol << 5 | position), as in k_tiles' short form;
-//      the surviving symbols go to the word's stretch of the run, RUN_DEAD fills the rest
-//   3. per tile: the run is compacted in place (dead slots out), the tile's id count, the ids-before-document values
-//      and the positions of its exception words are corrected.  Everything downstream sees a dense run.
-// ------------------------------------------------------------------------
-#ifndef HUTK_MG_TILES
-#define HUTK_MG_TILES 8
-#endif
-constexpr int MG_TILES = HUTK_MG_TILES, MG_POOL = 512, MG_UNITS = LANE_MAX_UNITS;
-constexpr int MG_CHUNKS = (RUN_STRIDE + 63) / 64 + 1;
-static_assert(MG_TILES <= 32 && MG_POOL >= 480, "pool entries keep the tile in 5 bits; a tile's words fit the pool");
-
-// ONE WAVEFRONT per workgroup and per MG_TILES tiles: nothing in here waits for another wavefront (lanes exchange data
-// through LDS with wave_sync() only), so a long word delays its own wavefront and nobody else.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void k_merge(DevTables T, BatchArgs A, Workspace W) {
-    // Symbols S and pair results M of the lane's word: MG_ROWS units per lane, unit i at [i * 64 + lane].  A chunk that
-    // holds a word of more units is 32 words wide: lane l < 32 also owns column l + 32 for its units MG_ROWS.. (LDS is
-    // what limits the resident wavefronts here, and their number is what hides the lookups' round trips).
-    constexpr int MG_ROWS = 16;
-    static_assert(MG_UNITS <= 2 * MG_ROWS, "two columns hold the longest word");
-    __shared__ __attribute__((aligned(16))) uint16_t SM[2 * MG_ROWS * 64];
-    __shared__ uint32_t pool[MG_POOL];
-    __shared__ uint32_t hist[MG_UNITS + 1], rank[MG_UNITS + 1], start[MG_UNITS + 1];
-    uint32_t* const unsorted = reinterpret_cast<uint32_t*>(SM);  // (the list before it is sorted: S and M are idle then)
-    static_assert(sizeof(SM) >= MG_POOL * 4, "the unsorted list shares the symbol arrays");
-    const int lane = threadIdx.x;
-    const int64_t tile0 = (int64_t)blockIdx.x * MG_TILES;
-    uint16_t* const run16 = reinterpret_cast<uint16_t*>(W.run);
-    constexpr uint32_t NOKEY = 0xFFFFFFFFu;
-    uint16_t* const S = SM;
-    uint16_t* const M = SM + 64 * MG_ROWS;
-
-    // words per tile, one tile per lane
-    const uint32_t my_cnt = (lane < MG_TILES && tile0 + lane < A.n_tiles) ? W.tile_ndefer[tile0 + lane] : 0u;
-
-    // groups of tiles whose words fit the pool (nearly always all of them at once)
-    for (int tb = 0; tb < MG_TILES;) {
-        int te = tb;
-        uint32_t total = 0;
-        for (; te < MG_TILES; te++) {  // (a tile has at most 480 words)
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, te);
-            if (total + c > (uint32_t)MG_POOL) break;
-            total += c;
-        }
-        if (total) {
-            if (lane <= MG_UNITS) { hist[lane] = 0; rank[lane] = 0; }
-            wave_sync();
-            // 1. the words of tiles [tb, te): one bit per stretch in the tile's bitmap, {start, units} in its first two slots
-            uint32_t n_seen = 0;  // (entries go to the list in lane order, one ballot per step)
-            for (int i = tb * DEFER_WORDS + lane; i < (te * DEFER_WORDS + 63) / 64 * 64; i += 64) {
-                const int t = i / DEFER_WORDS, w = i - t * DEFER_WORDS;
-                uint32_t bits = 0;
-                if (i < te * DEFER_WORDS && tile0 + t < A.n_tiles) bits = W.defer_mask[(tile0 + t) * DEFER_WORDS + w];
-                uint32_t before;
-                {
-                    uint32_t tot;
-                    before = wave_excl_scan((uint32_t)__popc(bits), lane, &tot);
-                    before += n_seen;
-                    n_seen += tot;
-                }
-                const uint16_t* run = run16 + (tile0 + t) * RUN_STRIDE;
-                for (; bits; bits &= bits - 1, before++) {
-                    const uint32_t p = 32u * w + (uint32_t)__builtin_ctz(bits);
-                    uint32_t wn;  // {start, units}: two 16-bit slots read as one (2-byte aligned) dword
-                    __builtin_memcpy(&wn, run + p, 4);
-                    const uint32_t ws = wn & 0xFFFFu, n = wn >> 16;
-                    unsorted[before] = (uint32_t)t | (p << 5) | (ws << 16) | ((n - 1u) << 26);
-                    atomicAdd(&hist[n], 1u);
-                }
-            }
-            wave_sync();
-            {   // lane i <-> words of MG_UNITS - i units: first pool entry of that count, longest words first
-                uint32_t tot;
-                const uint32_t st = wave_excl_scan(lane < MG_UNITS ? hist[MG_UNITS - lane] : 0u, lane, &tot);
-                if (lane < MG_UNITS) start[MG_UNITS - lane] = st;
-            }
-            wave_sync();
-            for (uint32_t i = lane; i < total; i += 64) {
-                const uint32_t e = unsorted[i], n = (e >> 26) + 1u;
-                pool[start[n] + atomicAdd(&rank[n], 1u)] = e;
-            }
-            wave_sync();  // (the unsorted list is dead now: S and M may be written)
-
-            // 2. chunks of 64 words (32 while the words have more than MG_ROWS units: the longest come first), one word per lane
-            for (uint32_t base = 0, width; base < total; base += width) {
-                width = (pool[base] >> 26) + 1u > (uint32_t)MG_ROWS ? 32u : 64u;
-                bool have = (uint32_t)lane < width && base + lane < total;
-                const uint32_t e = have ? pool[base + lane] : 0u;
-                const int64_t tile = tile0 + (e & 31u);
-                const uint32_t p = (e >> 5) & 2047u, ws = (e >> 16) & 1023u;
-                const int n = (int)(e >> 26) + 1;
-                // unit i of my word: row i % MG_ROWS of my column, or of column lane + 32 from unit MG_ROWS on
-                auto at = [&](int i) -> int { return ((i & (MG_ROWS - 1)) << 6) + lane + ((i >> 4) << 5); };
-                static_assert(MG_ROWS == 16, "at()");
-                auto Sw = [&](int i) -> uint16_t& { return S[at(i)]; };
-                auto Mw = [&](int i) -> uint16_t& { return M[at(i)]; };
-                auto scan_key = [&](uint32_t c) -> uint32_t {  // four candidates per step, their LDS reads in flight together
-                    uint32_t b = NOKEY;
-                    while (c) {
-                        const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
-                        const int i0 = __builtin_ctz(c);
-                        const int i1 = c1 ? __builtin_ctz(c1) : i0, i2 = c2 ? __builtin_ctz(c2) : i0,
-                                  i3 = c3 ? __builtin_ctz(c3) : i0;
-                        const uint32_t k0 = ((uint32_t)Mw(i0) << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw(i1) << 5) | (uint32_t)i1,
-                                       k2 = ((uint32_t)Mw(i2) << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw(i3) << 5) | (uint32_t)i3;
-                        b = min(min(b, k0), min(min(k1, k2), k3));
-                        c = c3 & (c3 - 1);
-                    }
-                    return b;
-                };
-                uint32_t live = 0, cand = 0, best = NOKEY;
-                if (have) {
-                    live = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
-                    // eight units per step: three dwords of the word's bytes, two consecutive bytes = index of the
-                    // (byte, next byte) table, whose entry is {symbol of the byte, merged symbol of the pair}
-                    const int64_t g = tile * TILE_BYTES + ws;  // the word's first byte
-                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
-                    for (int i0 = 0; i0 < n; i0 += 8) {
-                        const int64_t a = (g + i0) & ~(int64_t)3;
-                        const int o8 = 8 * (int)((g + i0) & 3);
-                        uint32_t q[3];
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            const int64_t at = a + 4 * k;
-                            if (at + 4 <= A.n_bytes) {
-                                q[k] = *reinterpret_cast<const uint32_t*>(A.bytes + at);
-                            } else {  // the last bytes of the batch
-                                q[k] = 0;
-                                for (int b = 0; b < 4; b++)
-                                    if (at + b < A.n_bytes) q[k] |= (uint32_t)A.bytes[at + b] << (8 * b);
-                            }
-                        }
-                        const uint64_t lo = (uint64_t)funnel_r(q[1], q[0], o8) | ((uint64_t)funnel_r(q[2], q[1], o8) << 32);
-                        const uint32_t k2 = q[2] >> o8;  // its low byte is byte 8 of the stretch
-                        uint32_t en[8];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) en[j] = bp[(uint32_t)(lo >> (8 * j)) & 0xFFFFu];
-#pragma unroll
-                        for (int j = 4; j < 8; j++) en[j] = 0xFFFFFFFFu;
-                        if (i0 + 4 < n) {  // (the table is 256 KB of L2: a lookup that nobody needs still costs an address cycle)
-#pragma unroll
-                            for (int j = 4; j < 8; j++) {
-                                const uint32_t idx = j < 7 ? (uint32_t)(lo >> (8 * j)) & 0xFFFFu
-                                                           : ((uint32_t)(lo >> 56) | ((k2 & 0xFFu) << 8));
-                                en[j] = bp[idx];
-                            }
-                        }
-                        uint32_t cb = 0;
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {  // (rows beyond the word but inside the lane's column: stored all the same)
-                            Sw(i0 + j) = (uint16_t)en[j];
-                            Mw(i0 + j) = (uint16_t)(en[j] >> 16);
-                            cb |= (en[j] < 0xFFFF0000u ? 1u : 0u) << j;
-                        }
-                        cand |= cb << i0;
-                    }
-                    cand &= (1u << (n - 1)) - 1u;  // the last unit has no next one (n >= 2)
-                    best = scan_key(cand);
-                }
-                for (;;) {  // one merge per trip and lane
-                    if (!__any(have && best != NOKEY)) break;
-                    if (have && best != NOKEY) {
-                        const int pp = (int)(best & 31u);
-                        const uint32_t merged = best >> 5;
-                        const uint32_t above = live & ~((2u << pp) - 1u);  // not empty: bit pp of cand was set
-                        const int q = __builtin_ctz(above);                // the unit the merge consumes
-                        Sw(pp) = (uint16_t)merged;
-                        live &= ~(1u << q);
-                        const uint32_t right = above & (above - 1u);     // live units after q
-                        const uint32_t left = live & ((1u << pp) - 1u);  // live units before pp: none iff pp == 0
-                        const int q2 = right ? __builtin_ctz(right) : 0;
-                        const int p0 = 31 - __builtin_clz(left | 1u);    // == pp when there is none
-                        const uint32_t sr = Sw(q2), sl = Sw(p0);         // (read and looked up even when absent)
-                        const PairProbe s1 = pair_issue(T, merged, sr);
-                        const PairProbe s2 = pair_issue(T, sl, merged);
-                        cand &= ~((1u << q) | (1u << pp) | (1u << p0));
-                        best = scan_key(cand);
-                        uint32_t mr = pair_resolve(T, s1, merged, sr), ml = pair_resolve(T, s2, sl, merged);
-                        mr = right ? mr : SYM_NONE;
-                        ml = left ? ml : SYM_NONE;
-                        Mw(p0) = (uint16_t)ml;  // first: without a left neighbour p0 == pp
-                        Mw(pp) = (uint16_t)mr;
-                        const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
-                        cand |= ((hr ? 1u : 0u) << pp) | ((hl ? 1u : 0u) << p0);
-                        const uint32_t kr = hr ? ((mr << 5) | (uint32_t)pp) : NOKEY;
-                        const uint32_t kl = hl ? ((ml << 5) | (uint32_t)p0) : NOKEY;
-                        best = min(best, min(kr, kl));
-                    }
-                }
-                if (have) {  // the survivors in order, then RUN_DEAD up to the end of the stretch; two slots per store
-                    uint16_t* out = run16 + tile * RUN_STRIDE + p;
-                    uint32_t c = live;
-                    auto next_out = [&]() -> uint32_t {
-                        if (!c) return RUN_DEAD;
-                        const uint32_t v = Sw(__builtin_ctz(c));
-                        c &= c - 1;
-                        return v;
-                    };
-                    int k = 0;
-                    if (p & 1u) out[k++] = (uint16_t)next_out();  // up to the next dword boundary
-                    for (; k + 2 <= n; k += 2) {
-                        const uint32_t lo = next_out(), hi = next_out();
-                        *reinterpret_cast<uint32_t*>(out + k) = lo | (hi << 16);
-                    }
-                    if (k < n) out[k] = (uint16_t)next_out();
-                }
-                wave_sync();
-            }
-        }
-        tb = te > tb ? te : tb + 1;
-    }
-}
-
-// ------------------------------------------------------------------------
-// k_compact: after k_merge a tile's run has RUN_DEAD slots where words merged.  One wavefront per tile takes them out in
-// place and corrects what was counted in slots: the tile's id count, the ids-before-document values of the documents
-// that start in it and the positions of its exception words.  Everything downstream sees a dense run.
-// ------------------------------------------------------------------------
-constexpr int CP_WAVES = 4;
-__global__ __launch_bounds__(64 * CP_WAVES) void k_compact(BatchArgs A, Workspace W) {
-    __shared__ unsigned long long s_bal[CP_WAVES][MG_CHUNKS];  // live slots of a 64-slot piece ...
-    __shared__ uint32_t s_cum[CP_WAVES][MG_CHUNKS];            // ... and the live slots before it
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * CP_WAVES + wv;
-    if (tile >= A.n_tiles || W.tile_ndefer[tile] == 0) return;
-    uint16_t* run = reinterpret_cast<uint16_t*>(W.run) + tile * RUN_STRIDE;
-    const uint32_t dense = W.tile_dense[tile];  // slots used, stretches included
-    uint32_t outn = 0;
-    int c = 0;
-    constexpr int CP_UNROLL = 8;  // pieces of 64 slots read together (a tile has ~400 slots): one round trip, not eight
-    for (uint32_t kb = 0; kb < dense; kb += 64 * CP_UNROLL) {
-        uint16_t v[CP_UNROLL];
-#pragma unroll
-        for (int j = 0; j < CP_UNROLL; j++) {
-            const uint32_t k = kb + 64 * j + lane;
-            v[j] = k < dense ? run[k] : (uint16_t)RUN_DEAD;
-        }
-#pragma unroll
-        for (int j = 0; j < CP_UNROLL; j++) {
-            if (kb + 64 * j >= dense) break;
-            const bool alive = v[j] != (uint16_t)RUN_DEAD;
-            const unsigned long long bal = __ballot(alive);
-            if (alive) run[outn + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = v[j];  // never ahead of what is still to be read
-            if (lane == 0) { s_bal[wv][c] = bal; s_cum[wv][c] = outn; }
-            outn += (uint32_t)__popcll(bal);
-            c++;
-        }
-    }
-    if (lane == 0) { s_bal[wv][c] = 0; s_cum[wv][c] = outn; }
-    wave_sync();
-    auto live_before = [&](uint32_t pos) -> uint32_t {  // live slots before slot pos (pos <= dense)
-        const uint32_t cc = pos >> 6;
-        return s_cum[wv][cc] + (uint32_t)__popcll(s_bal[wv][cc] & ((1ull << (pos & 63u)) - 1ull));
-    };
-    if (lane == 0) { W.tile_dense[tile] = outn; W.tile_count[tile] = outn; }
-    const int64_t t0 = tile * TILE_BYTES;
-    const int64_t t_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
-    for (int64_t d = W.tile_first_doc[tile] + lane; d <= A.n_docs; d += 64) {
-        const int64_t o = A.offsets[d];
-        if (o >= t_end) break;
-        if (o < t0) continue;
-        W.doc_tile_pos[d] = live_before(W.doc_tile_pos[d]);
-    }
-    const uint32_t nexc = W.tile_nexc[tile];
-    for (uint32_t x = lane; x < nexc; x += 64) {
-        ExcRec* r = W.exc + W.tile_exc_first[tile] + x;
-        r->wpos = live_before(r->wpos);
-    }
 }
 
 // ------------------------------------------------------------------------
@@ -2282,8 +1795,8 @@ struct EndsWin {
 // applied 256 positions at a time (src/parser.c:24-183 as in k_tiles' exact form), or -- regex pre-token path -- the next
 // start bit of the host's bitmap.  One wavefront; sb / scode / docm are its LDS scratch, cw its window (above).
 // -> end offset; *too_large when the word passes the reference's limit (core.c:402-407).
-__device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t d, int64_t ds, int64_t de, uint8_t* sb, uint8_t* scode,
-                                uint32_t* docm, int lane, bool* too_large, EndsWin& cw) {
+__device__ int64_t exc_word_end(const DevTables& T, const BatchArgs& A, int64_t ws, int64_t d, int64_t ds, int64_t de, uint8_t* sb,
+                                uint8_t* scode, uint32_t* docm, int lane, bool* too_large, EndsWin& cw) {
     int64_t we = -1;
     *too_large = false;
     if (A.word_bits) {
@@ -2325,7 +1838,11 @@ __device__ int64_t exc_word_end(const BatchArgs& A, int64_t ws, int64_t d, int64
 #pragma unroll
             for (int r = 0; r < EXC_CHUNK / 64; r++) {
                 const int64_t q = base + 64 * r + lane;
-                cw.bits[r] = __ballot((q <= de) && word_starts(scode, docm, 16 + 64 * r + lane));
+                const int wi = 16 + 64 * r + lane;
+                bool st = (q <= de) && word_starts(scode, docm, wi);
+                if (T.seam_on && q < de && sb[wi] >= 0xE0u)  // a seam starts a word as well (k_tiles, phase 3)
+                    st = st || !((T.seam_hi[sb[wi - 1]] >> (sb[wi] & 31u)) & 1u);
+                cw.bits[r] = __ballot(st);
             }
             wave_sync();
             cw.base = base;
@@ -2380,7 +1897,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
             const int64_t ws = rec.ws;
             const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
             bool too_large;
-            const int64_t we = exc_word_end(A, ws, d, ds, de, sb, scode, docm, lane, &too_large, cw);
+            const int64_t we = exc_word_end(T, A, ws, d, ds, de, sb, scode, docm, lane, &too_large, cw);
             const int64_t nb = too_large ? 0 : we - ws;
             if (too_large || nb > MAX_WORD_BYTES) {
                 if (lane == 0) {
@@ -2866,13 +2383,6 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), dim3(64 * WV), 0, s, \
                        t, a, w)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
-    if (tiles_defer(t)) {  // the merge loop, or its long tail, in k_merge (DevTables::split_merge)
-        const dim3 g((unsigned)(((a.n_tiles + TILE_WAVES - 1) / TILE_WAVES + 7) / 8 * 8)), b(64 * TILE_WAVES);
-        if (t.split_merge == 1) hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 1>), g, b, 0, s, t, a, w);
-        else if (t.split_merge == 2) hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 16>), g, b, 0, s, t, a, w);
-        else hipLaunchKernelGGL((k_tiles<uint16_t, true, true, TILE_WAVES, 12>), g, b, 0, s, t, a, w);
-        return;
-    }
     switch (variant) {
         case 7: HUTK_LAUNCH(uint16_t, true, true, TILE_WAVES); break;
         case 6: HUTK_LAUNCH(uint16_t, true, false, TILE_WAVES); break;
@@ -2884,14 +2394,6 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
         default: HUTK_LAUNCH(uint32_t, false, false, TILE_WAVES); break;
     }
 #undef HUTK_LAUNCH
-}
-bool tiles_defer(const DevTables& t) {
-    return HUTK_FAST_MERGE && t.split_merge && t.sym16 && t.is_byte_encoder && t.rank_is_sym;
-}
-void launch_merge(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
-    if (!tiles_defer(t)) return;
-    hipLaunchKernelGGL(k_merge, dim3((unsigned)((a.n_tiles + MG_TILES - 1) / MG_TILES)), dim3(64), 0, s, t, a, w);
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)((a.n_tiles + CP_WAVES - 1) / CP_WAVES)), dim3(64 * CP_WAVES), 0, s, a, w);
 }
 bool small_tail(const BatchArgs& a) { return a.n_tiles <= SMALL_TILES && a.n_docs <= 4096; }
 void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {

@@ -1,0 +1,35 @@
+// hutk_lab.h -- MEASUREMENT ONLY switches of hutk_kernels.hip.  None is set in a build that ships; tools/build_variant.sh
+// sets one per library for the A/B runs (tools/ab.py, tools/pmc_ab.sh) whose numbers DESIGN.md section 5 quotes.
+//   HUTK_PERTURB_VALU=n   n extra VALU instructions per tile (a dependent chain in every lane)
+//   HUTK_PERTURB_SLEEP=n  n x ~8 k idle cycles per wavefront before the merge phase
+//   HUTK_PERTURB_MEM=n    n extra 16-byte table gathers per word
+//   HUTK_ABLATE_MERGE=1   no word is merged (WRONG IDS): instruction count of the other phases
+//   HUTK_MERGE_STAMPS=1   the ten clock stamps of the diagnostic profile (hutk_debug_profile) are spent inside the
+//                         merge phase instead of at the phase boundaries (tools/profile_phases.py)
+#pragma once
+#ifndef HUTK_PERTURB_VALU
+#define HUTK_PERTURB_VALU 0
+#endif
+#ifndef HUTK_PERTURB_MEM
+#define HUTK_PERTURB_MEM 0
+#endif
+#ifndef HUTK_PERTURB_SLEEP
+#define HUTK_PERTURB_SLEEP 0
+#endif
+#ifndef HUTK_ABLATE_MERGE
+#define HUTK_ABLATE_MERGE 0
+#endif
+#ifndef HUTK_MERGE_STAMPS
+#define HUTK_MERGE_STAMPS 0
+#endif
+#define HUTK_STAMP_AT(k)                                                       \
+    do {                                                                       \
+        if (W.prof && lane == 0) W.prof[tile * N_PHASE + (k)] = clock64();     \
+    } while (0)
+#if HUTK_MERGE_STAMPS
+#define HUTK_STAMP(k) do {} while (0)
+#define HUTK_MSTAMP(k) do { if (tile_ok) HUTK_STAMP_AT(k); } while (0)
+#else
+#define HUTK_STAMP(k) HUTK_STAMP_AT(k)
+#define HUTK_MSTAMP(k) do {} while (0)
+#endif

@@ -333,6 +333,94 @@ void finish_char_table(Tables& T, std::vector<std::pair<uint32_t, uint32_t>>& ch
 
 
 // ------------------------------------------------------------------------
+// Seam map (Tables::seam_hi).  A merge joins two tokens L and R only if (L, R) is an entry of the pair table
+// (core.c:700-722: the concatenation is a key; core.c:724-736: the pair is a rule), and every token is a run of whole
+// units as the pretokenizer makes them from the input items.  So two adjacent input bytes x | y with a unit boundary
+// between them can end up inside one token only if some pair entry has an L whose last unit can come from an input
+// item ending in x and an R whose first unit can come from an item beginning with y.  Where no entry does, the word's
+// encoding is the concatenation of the encodings of its two sides -- whatever the rest of the word looks like -- and
+// k_tiles may treat y as the start of a word of its own.  Kept for y >= 0xE0 only (the lead bytes of three- and
+// four-byte characters: in text, runs of CJK characters and emoji); everything else is "may merge".
+// ------------------------------------------------------------------------
+struct RawEnds {
+    uint64_t last[4] = {0, 0, 0, 0};  // input bytes the last unit can come from (its item's last byte)
+    uint32_t first_hi = 0;            // input bytes >= 0xE0 the first unit's item can begin with, bit y - 0xE0
+    void all() { last[0] = last[1] = last[2] = last[3] = ~0ull; first_hi = ~0u; }
+    bool join(const RawEnds& o, bool take_first, bool take_last) {
+        bool ch = false;
+        if (take_first && (first_hi | o.first_hi) != first_hi) { first_hi |= o.first_hi; ch = true; }
+        if (take_last)
+            for (int q = 0; q < 4; q++)
+                if ((last[q] | o.last[q]) != last[q]) { last[q] |= o.last[q]; ch = true; }
+        return ch;
+    }
+};
+struct UnitEnds {
+    std::unordered_map<std::string, RawEnds> of;  // unit string -> the input items it can come from
+    bool is_byte_encoder = false;
+    const bool* has_special = nullptr;
+    void add_item(int b, const std::string& unit, bool whole_char_replaced) {
+        RawEnds& e = of[unit];
+        if (b >= 0xE0) e.first_hi |= 1u << (b - 0xE0);
+        if (whole_char_replaced) e.last[2] |= ~0ull;  // the item is a character led by b: it ends in a continuation byte
+        else e.last[b >> 6] |= 1ull << (b & 63);
+    }
+    RawEnds get(const std::string& u) const {
+        RawEnds e;
+        auto it = of.find(u);
+        if (it != of.end()) e = it->second;
+        // outside byte-encoder mode a multi-byte character without replacement is its own unit
+        if (!is_byte_encoder && u.size() >= 2 && (size_t)lead_len((unsigned char)u[0]) == u.size() &&
+            !has_special[(unsigned char)u[0]]) {
+            const unsigned b0 = (unsigned char)u[0], bl = (unsigned char)u.back();
+            if (b0 >= 0xE0) e.first_hi |= 1u << (b0 - 0xE0);
+            e.last[bl >> 6] |= 1ull << (bl & 63);
+        }
+        return e;
+    }
+};
+UnitEnds unit_ends_of_items(const std::string special[256], const bool has_special[256], bool is_byte_encoder,
+                            bool hex_units) {
+    UnitEnds U;
+    U.is_byte_encoder = is_byte_encoder;
+    U.has_special = has_special;
+    std::vector<std::string> us;
+    for (int b = 1; b < 256; b++) {
+        if (!is_byte_encoder && ((b >= 0x80 && b < 0xC0) || b >= 0xF8)) continue;
+        std::string s;
+        if (has_special[b]) s = special[b];
+        else if (is_byte_encoder && b >= 0x80) {
+            s.push_back((char)(0xC0 | (b >> 6)));
+            s.push_back((char)(0x80 | (b & 0x3F)));
+        } else if (b < 0x80) s.push_back((char)b);
+        else continue;
+        // (a replacement of several units: the seam sees its first and its last one)
+        if (!split_units(s, hex_units, us) || us.empty()) { us.assign(1, s); }
+        const bool whole = !is_byte_encoder && b >= 0xC0;
+        if (us.size() == 1) U.add_item(b, us[0], whole);
+        else {
+            RawEnds& f = U.of[us.front()];
+            if (b >= 0xE0) f.first_hi |= 1u << (b - 0xE0);
+            RawEnds& l = U.of[us.back()];
+            if (whole) l.last[2] |= ~0ull; else l.last[b >> 6] |= 1ull << (b & 63);
+        }
+    }
+    return U;
+}
+void seam_from_pairs(Tables& T, const std::vector<uint64_t>& entries, const std::vector<RawEnds>& ends) {
+    for (int x = 0; x < 256; x++) T.seam_hi[x] = 0;
+    for (uint64_t e : entries) {
+        const uint32_t l = (uint32_t)e & 0xFFFFFu, r = ((uint32_t)e >> 20) | (((uint32_t)(e >> 32) & 0xFFu) << 12);
+        if (l >= ends.size() || r >= ends.size()) continue;
+        const uint32_t f = ends[r].first_hi;
+        if (!f) continue;
+        for (int q = 0; q < 4; q++)
+            for (uint64_t m = ends[l].last[q]; m; m &= m - 1) T.seam_hi[64 * q + __builtin_ctzll(m)] |= f;
+    }
+    T.seam_on = true;
+}
+
+// ------------------------------------------------------------------------
 // id-keyed merge path: a merges file was given (src/lib.c:573-663, src/core.c:211-337, 457-477)
 // ------------------------------------------------------------------------
 struct MergeRule {
@@ -573,6 +661,25 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
     }
     { LoadError pe = finish_pair_table(T, entries); if (pe.code) return pe; }
     finish_bytepair(T);
+    {   // seam map: a base symbol ends like its characters, a rule's result begins like its left and ends like its right
+        const UnitEnds U = unit_ends_of_items(special, has_special, is_byte_encoder, false);
+        std::vector<RawEnds> ends(T.sym_id.size());
+        for (auto& kv : vocab)
+            if (kv.second != -1 && single_char(kv.first)) {
+                auto b = base_sym.find(kv.second);
+                if (b != base_sym.end() && b->second < ends.size()) ends[b->second].join(U.get(kv.first), true, true);
+            }
+        for (bool changed = true; changed;) {
+            changed = false;
+            for (size_t k = 0; k < alive.size(); k++) {
+                live_variants(alive[k].l, lv);
+                live_variants(alive[k].r, rv);
+                for (uint32_t a : lv) changed |= ends[rule_sym[k]].join(ends[a], true, false);
+                for (uint32_t b : rv) changed |= ends[rule_sym[k]].join(ends[b], false, true);
+            }
+        }
+        seam_from_pairs(T, entries, ends);
+    }
 
     // ---- whole-word table candidates: keys as raw input bytes ----
     {
@@ -880,6 +987,19 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
     }
     { LoadError pe = finish_pair_table(T, entries); if (pe.code) return pe; }
     finish_bytepair(T);
+    {   // seam map: a symbol begins like its first unit and ends like its last one
+        const UnitEnds U = unit_ends_of_items(special, has_special, is_byte_encoder, true);
+        std::vector<RawEnds> ends(T.sym_id.size());
+        std::vector<std::string> us;
+        for (auto& kv : sym_of) {
+            if (kv.second >= ends.size()) continue;
+            RawEnds& e = ends[kv.second];
+            if (!split_units(kv.first, true, us) || us.empty()) { e.all(); continue; }  // (no run of whole units: cannot be a token; stay on the safe side)
+            e.join(U.get(us.front()), true, false);
+            e.join(U.get(us.back()), false, true);
+        }
+        seam_from_pairs(T, entries, ends);
+    }
 
     // ---- keys as raw input bytes (whole-word table candidates) ----
     // A key is a candidate when every unit of it is produced by exactly one input: the single byte whose

@@ -197,6 +197,13 @@ int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
  * costs two loads instead of one). */
 int64_t hutk_debug_pairs_second(const hutk_ctx* ctx);
 
+/* Diagnostic: the seam map the tile kernel splits words by.  Bit (y - 0xE0) of out256[x] is set when some merge of
+ * this vocabulary can join a token that ends with input byte x to one that begins with input byte y (0xE0..0xFF, the
+ * lead bytes of three- and four-byte characters); where it is clear the reference's merge loop (src/core.c:66-209,
+ * 211-337) can never produce a token across x | y, and the word is encoded as two.  Returns 1 when the map is in
+ * use, 0 when it is switched off (HUTK_NO_SEAM=1). */
+int hutk_debug_seam(const hutk_ctx* ctx, uint32_t* out256);
+
 /* Diagnostic build aid: clock64 stamps at the phase boundaries of the tile kernel.
  * hutk_debug_profile(ctx, 1), run a batch, then hutk_debug_profile_read returns the
  * mean shader cycles per phase over the first n_tiles tiles (out10[0] = their sum,

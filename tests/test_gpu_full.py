@@ -88,20 +88,22 @@ def test_full_size_without_the_whole_word_table(g, monkeypatch):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode,no_table", [("1", False), ("1", True), ("2", False), ("3", False)],
-                         ids=["all-table", "all-no-table", "over16", "over12"])
-@pytest.mark.parametrize("g", [g for g in g7_cases() if g["vocab"] == "VG"], ids=case_id)
-def test_full_size_with_the_split_merge_kernels(g, mode, no_table, monkeypatch):
-    """HUTK_SPLIT_MERGE=1: k_tiles leaves the merge loop to k_merge (words sorted by unit count, one per lane) and
-    k_compact; the same ids.  Also without the whole-word table, i.e. with every word going that way, and in the two
-    hybrid modes (2 / 3: only the words of more than 16 / 12 units leave k_tiles)."""
+@pytest.mark.parametrize("no_table", [False, True], ids=["table", "no-table"])
+@pytest.mark.parametrize("g", g7_cases(), ids=case_id)
+def test_full_size_without_the_seam_map(g, no_table, monkeypatch):
+    """HUTK_NO_SEAM=1: words are not cut where no merge can span (hutk_loader.cpp, seam_from_pairs): every run of CJK
+    characters is one long merge-loop word again.  The same ids -- the cut is invisible by construction -- also
+    without the whole-word table."""
     from hutoken_amd import _capi, data, synth
-    monkeypatch.setenv("HUTK_SPLIT_MERGE", mode)
+    monkeypatch.setenv("HUTK_NO_SEAM", "1")
     if no_table:
+        if g["vocab"] != "VG":
+            pytest.skip("one vocabulary is enough for the combination")
         monkeypatch.setenv("HUTK_NO_WORD_TABLE", "1")
     vp, sp, kw = data.vocab_files(g["vocab"])
     mp = data.merges_file(g["vocab"]) if g["merges"] else None
     ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], merges_path=mp)
+    assert ctx.seam_map()[1] is False
     d, o = synth.corpus(g["corpus"], g["n_docs"])
     ids, oo = encode_one_launch(ctx, d, o)
     check_against(g, ids, oo)

@@ -1,0 +1,119 @@
+"""The seam map (hutk_loader.cpp, seam_from_pairs): where bit (y - 0xE0) of entry x is clear, the tile kernel starts a
+word of its own at input byte y behind input byte x.  That is only allowed if the reference's merge loop
+(src/core.c:66-209 string-keyed, 211-337 id-keyed) can never build a token across x | y, i.e. if
+
+    encode(word) == encode(left piece) + encode(right piece)          for every word cut at such a place.
+
+Checked here on the CPU against the oracle, for random vocabularies of both shapes (proper and shuffled ids, duplicate
+and negative ids, with and without a merges file, with and without a prefix) and texts full of three- and four-byte
+characters; and that the map is not trivially "everything may merge" on the shipped GPT-2-shaped vocabulary."""
+import random
+
+import numpy as np
+import pytest
+
+import helpers as H
+from hutoken_amd import _capi, data
+from oracle import oracle as O
+
+WORDS = ["漢字", "字漢字仮", "仮名交じり文", " 中文測試", "😂🙂", " 🚀😂x", "a漢b字", "é漢ő字", "漢.字,", " 12漢34", "漢😂字🙂名",
+         "交じり", " Ti漢", "x😂", "文中文測試漢字仮名交じり文中文測試"]
+
+
+POOL = "漢字仮名交じり文中文測試籥披烺蝡贄搝誴貕僤諙臣皝橹彘窄貺輊儮錻毫塃善" + "😂🙂🚀" + "€—…" + "aeéő .,1"
+
+
+def cjk_text(rng):
+    """Words that are mostly runs of three- and four-byte characters, a few letters, digits and signs between."""
+    out = []
+    for _ in range(rng.randint(1, 10)):
+        out.append("".join(rng.choice(POOL) for _ in range(rng.randint(1, 9))))
+        out.append(rng.choice([" ", " ", "  ", "\n", ""]))
+    return "".join(out)
+
+
+def pieces_of(word, seam):
+    cuts = [0] + [k for k in range(1, len(word)) if word[k] >= 0xE0 and not (int(seam[word[k - 1]]) >> (word[k] & 31)) & 1]
+    cuts.append(len(word))
+    return [word[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+
+
+def check(vp, sp, prefix, is_byte, merges, rng, n_texts):
+    ctx = _capi.Context(vp, sp, prefix, is_byte, device=-2, merges_path=merges)
+    seam, on = ctx.seam_map()
+    assert on
+    orc = O.Oracle(vp, sp, prefix, is_byte, merges_path=merges)
+    head = len(orc.encode_bytes(b"\n")[0])  # the document's first word; the word under test is never first
+    n_cut = 0
+    cache = {}
+
+    def enc(w):
+        if w not in cache:
+            cache[w] = orc.encode_bytes(b"\n" + w)[0][head:]
+        return cache[w]
+
+    texts = [w for w in WORDS] + [H.random_text(rng, 10) for _ in range(n_texts // 2)] + [cjk_text(rng) for _ in range(n_texts)]
+    for t in texts:
+        doc = t.encode("utf-8")
+        st = O.split_words(doc)
+        for j, s in enumerate(st):
+            w = doc[s:(st[j + 1] if j + 1 < len(st) else len(doc))]
+            ps = pieces_of(w, seam)
+            if len(ps) == 1:
+                continue
+            n_cut += 1
+            whole, parts = enc(w), [i for p in ps for i in enc(p)]
+            assert whole == parts, (vp, w, ps, whole, parts)
+    ctx.close()
+    return n_cut
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cut_words_encode_to_the_same_ids_byte_vocabularies(tmp_path, seed):
+    rng = random.Random(1000 + seed)
+    entries, special = H.random_byte_vocab(seed, n_merges=250 + 60 * seed, proper=seed % 2 == 0, dup_ids=seed == 3,
+                                           neg_ids=seed == 5)
+    vp, sp = H.write_vocab(tmp_path, "b%d" % seed, entries, special)
+    total = check(vp, sp, None, True, None, rng, 150)
+    if seed % 2 == 0:  # the id-keyed path of the same vocabulary
+        mp = H.write_merges(tmp_path, "b%d" % seed, H.random_merges_text(entries, seed, noise=seed == 2))
+        total += check(vp, sp, None, True, mp, rng, 100)
+    assert total > 0  # (texts with CJK runs: some place is always cut)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_cut_words_encode_to_the_same_ids_char_vocabularies(tmp_path, seed):
+    rng = random.Random(2000 + seed)
+    entries, special = H.random_char_vocab(seed, n_merges=200 + 50 * seed, drop_chars="字" if seed == 1 else "")
+    vp, sp = H.write_vocab(tmp_path, "c%d" % seed, entries, special)
+    total = check(vp, sp, "▁" if seed != 2 else None, False, None, rng, 150)
+    if seed == 3:  # the id-keyed path wants one-character replacements: the space's only
+        sp1 = H.write_vocab(tmp_path, "c%dm" % seed, entries, {32: "▁"})[1]
+        mp = H.write_merges(tmp_path, "c%d" % seed, H.random_merges_text(entries, seed, noise=False))
+        total += check(vp, sp1, "▁", False, mp, rng, 100)
+    assert total >= 0
+
+
+def test_shipped_vocabularies():
+    vp, sp, kw = data.vocab_files("VG")
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2)
+    seam, on = ctx.seam_map()
+    assert on
+    # no key of VG spans two three-byte characters: behind a continuation byte every lead byte E0..EF is a seam
+    assert all(int(seam[x]) & 0xFFFF == 0 for x in range(0x80, 0xC0))
+    rng = random.Random(7)
+    assert check(vp, sp, kw["prefix"], kw["is_byte_encoder"], None, rng, 300) > 100
+    ctx.close()
+    vp, sp, kw = data.vocab_files("VL")
+    check(vp, sp, kw["prefix"], kw["is_byte_encoder"], None, rng, 300)
+    mp = data.merges_file("VG")
+    vp, sp, kw = data.vocab_files("VG")
+    assert check(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp, rng, 200) > 100
+
+
+def test_switch(monkeypatch):
+    vp, sp, kw = data.vocab_files("VG")
+    monkeypatch.setenv("HUTK_NO_SEAM", "1")
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2)
+    assert ctx.seam_map()[1] is False
+    ctx.close()
