@@ -299,6 +299,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 code "
                          "path where RCCL cannot run, e.g. two ranks sharing one GPU with HUTK_BENCH_DEVICE=0)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N = 1 only: initialise torch.distributed all the same (world size 1) and run the per-step all-gather "
+                         "of the id total, so that the RCCL branch executes on a one-GPU box (profiles/r03_n1_nccl_rehearsal.json)")
     ap.add_argument("--merges", action="store_true",
                     help="the id-keyed merge path (the vocabulary with its merges file, SURVEY 8 f-1) as the main workload")
     args = ap.parse_args()
@@ -318,12 +321,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    if world > 1:
+    dist_on = world > 1 or args.force_dist  # the collectives run (with --force-dist also in a world of one)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from hutoken_amd import _capi, data as hdata, sharding, synth
     vp, sp, kw = hdata.vocab_files(args.vocab)
@@ -348,7 +353,7 @@ def main():
 
         def step():
             batch.run()
-            if world > 1:  # the path's one exchange: per-rank id totals
+            if dist_on:  # the path's one exchange: per-rank id totals
                 d_tot.copy_(batch.d_oo[n_docs:n_docs + 1])
                 dist.all_gather(gathered, d_tot)
 
@@ -357,7 +362,7 @@ def main():
         sync()
         batch.check_err()
         tile_ms = []
-        if world > 1:
+        if dist_on:
             dist.barrier()
         sync()
         t0 = time.perf_counter()
@@ -365,11 +370,11 @@ def main():
             step()
             tile_ms.append(ctx.last_timing()[0])  # HIP events around k_tiles on the launch stream
         sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         total_bytes, total_ids = batch.n_bytes, batch.n_ids()
-        if world > 1:
+        if dist_on:
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
@@ -485,7 +490,7 @@ def main():
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(vp, sp, kw, args.corpus, min(args.cpu_docs, n_corpus), cores, mp)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -309,7 +309,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));
     HIP_TRY(c->w_exc_sym.reserve(exc_elems));
     HIP_TRY(c->w_exc_mrg.reserve(exc_elems));
-    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + 8));
+    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + n_tiles / 32 + 16));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     HIP_TRY(c->w_counters.reserve(8));
@@ -329,6 +329,8 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_exc_first = u + 3 * n_tiles;
     W.tile_nexc = u + 4 * n_tiles;
     W.exc_tiles = u + 5 * n_tiles;
+    W.tile_lastreal = u + 6 * n_tiles;
+    W.noreal_bits = u + 7 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
     W.scan_state = reinterpret_cast<unsigned long long*>(c->w_tile_i64.p + 2 * n_tiles + 2);
@@ -703,6 +705,7 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
         launch_exceptions(c->dt, A, W, s);
         launch_scan(A, W, s);
         launch_finish(c->dt, A, W, s);
+        if (n_bytes > MAX_WORD_BYTES) launch_cut(c->dt, A, W, s);
     }
     HIP_TRY(hipGetLastError());
     if (c->timing) {
@@ -726,8 +729,7 @@ int hutk_last_timing(hutk_ctx* c, float* ms_tile_kernel, float* ms_total) {
 static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                                int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status);
 static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
-                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
-                                  bool* redo_simple);
+                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status);
 
 // Batches of at least this many bytes go through the chunked path that overlaps the H2D copy of chunk c+1,
 // the kernels of chunk c and the D2H copy of chunk c-1 (worth it only when the copies dominate)
@@ -828,9 +830,7 @@ static int encode_batch_one(hutk_ctx* c, const uint8_t* bytes, const int64_t* of
         return encode_batch_regex(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
     if (c && !c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
         offsets[n_docs] >= PIPE_MIN_BYTES && !getenv("HUTK_NO_PIPELINE")) {
-        bool redo = false;
-        const int rc = encode_batch_pipelined(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, &redo);
-        if (!redo) return rc;
+        return encode_batch_pipelined(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
     }
     return encode_batch_simple(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
 }
@@ -985,7 +985,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
         return HUTK_OK;
     }
     if (strip) launch_dec_mark(D, s);
-    HIP_TRY(hipMemsetAsync(D.tile_state, 0, (size_t)n_tiles * 8, s));
+    HIP_TRY(hipMemsetAsync(D.tile_state, 0, (size_t)(n_tiles + 1) * 8, s));  // the tiles' states and the ticket counter behind them
     launch_dec(c->dec, D, s);
     HIP_TRY(hipGetLastError());
     return HUTK_OK;
@@ -1047,11 +1047,8 @@ void hutk_host_free(void* p) {
 // stream the offsets are rebased, the kernel sequence runs and the chunk's out_offsets are made absolute with
 // a device-side running total; the out_offsets come back on s_out (their last entry places the ids in the
 // caller's array), then the ids.  No per-document work on the host.
-// *redo_simple: a document was cut at an over-long word -- rare, and handled by the simple path's trimming.
 static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
-                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
-                                  bool* redo_simple) {
-    *redo_simple = false;
+                                  int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
     for (int64_t i = 0; i < n_docs; i++)
         if (offsets[i + 1] < offsets[i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
     const int64_t n_bytes = offsets[n_docs];
@@ -1103,7 +1100,6 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     hipStream_t sc = c->stream;
     HIP_TRY(hipMemsetAsync(P.base.p, 0, 8, sc));
     int64_t base = 0;  // ids of the chunks finalised so far
-    bool too_large = false;
     int dev_err = 0;
     auto finalize = [&](int ch) -> int {  // chunk ch: results to the caller's arrays
         const int b = ch & 1;
@@ -1114,8 +1110,7 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
         HIP_TRY(hipMemcpyAsync(&err, P.err[b].p, 4, hipMemcpyDeviceToHost, P.s_out));
         HIP_TRY(hipStreamSynchronize(P.s_out));
         const int64_t total = out_offsets[d0 + nd] - base;  // the chunk's offsets are absolute already
-        if (err == HUTK_E_WORD_TOO_LARGE) too_large = true;
-        else if (err && !dev_err) dev_err = err;
+        if (err && err != HUTK_E_WORD_TOO_LARGE && !dev_err) dev_err = err;  // (an over-long word is a note: k_cut has cut its document)
         if (base + total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
         if (total)
             HIP_TRY(hipMemcpyAsync(ids_out + base, P.ids[b].p, (size_t)total * 4, hipMemcpyDeviceToHost, P.s_out));
@@ -1160,10 +1155,6 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     }
     HIP_TRY(hipStreamSynchronize(P.s_out));
     out_offsets[n_docs] = base;
-    if (too_large && !dev_err) {
-        *redo_simple = true;  // the simple path trims the cut documents
-        return HUTK_OK;
-    }
     switch (dev_err) {
         case HUTK_OK: return HUTK_OK;
         case HUTK_E_NUL_BYTE: return set_err(dev_err, "a document contains a 0x00 byte");
@@ -1286,34 +1277,9 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
     int64_t total = out_offsets[n_docs];
     if (total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
     if (total) HIP_TRY(hipMemcpy(ids_out, c->s_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-    if (err == HUTK_E_WORD_TOO_LARGE) {
-        // The reference ends a document at a word longer than 262144 bytes and reports nothing
-        // (core.c:402-407 sets error_msg, core.c:503 clears it): drop the ids that follow the
-        // first such word of each affected document.  Rare; done here on the outputs.
-        uint32_t n_exc = 0;
-        HIP_TRY(hipMemcpy(&n_exc, c->w_counters.p, 4, hipMemcpyDeviceToHost));
-        std::vector<ExcRec> recs(n_exc);
-        if (n_exc) HIP_TRY(hipMemcpy(recs.data(), c->w_exc.p, n_exc * sizeof(ExcRec), hipMemcpyDeviceToHost));
-        std::vector<int64_t> keep((size_t)n_docs, -1);  // ids kept per cut document
-        for (auto& r : recs) {
-            if (r.tok_base >= 0) continue;
-            const int64_t d = (std::upper_bound(offsets, offsets + n_docs + 1, r.ws) - offsets) - 1;
-            if (d < 0 || d >= n_docs) continue;
-            const int64_t k = r.out_pos - out_offsets[d];
-            if (keep[d] < 0 || k < keep[d]) keep[d] = k;
-        }
-        int64_t w = 0;
-        for (int64_t d = 0; d < n_docs; d++) {
-            const int64_t a = out_offsets[d], b = out_offsets[d + 1];
-            const int64_t len = keep[d] >= 0 ? keep[d] : b - a;
-            if (w != a && len) memmove(ids_out + w, ids_out + a, (size_t)len * 4);
-            out_offsets[d] = w;
-            w += len;
-            if (status && keep[d] >= 0) status[d] = HUTK_DOC_WORD_TOO_LARGE;
-        }
-        out_offsets[n_docs] = w;
-        return HUTK_OK;
-    }
+    // (HUTK_E_WORD_TOO_LARGE is a note: the reference ends a document at a word longer than 262144 bytes and reports
+    // nothing, core.c:402-407, 503; k_cut has done that on the device and set the document's status)
+    if (err == HUTK_E_WORD_TOO_LARGE) return HUTK_OK;
     switch (err) {
         case HUTK_OK: return HUTK_OK;
         case HUTK_E_NUL_BYTE: return set_err(err, "a document contains a 0x00 byte");

@@ -104,8 +104,10 @@ struct Workspace {
     ExcRec* exc;               // [cap_exc]
     uint32_t* exc_quad;        // [cap_exc] exception words of at most 256 units for d_exc_quad (count: counters[4])
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in d_exc (count: counters[5])
-    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc
+    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc, [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
+    uint32_t* noreal_bits;     // [n_tiles / 32 + 1] bit t: tile t holds no word start of the reference's own (k_cut)
+    uint32_t* tile_lastreal;   // [n_tiles] position of the tile's last such start | ids before it << 16 (written when none follows in the halo)
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
     long long* prof;           // diagnostic: [n_tiles][10] clock64 stamps of k_tiles, or null
@@ -168,6 +170,9 @@ bool small_tail(const BatchArgs& a);
 void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // tile runs (+ exception words) -> ids_out, out_offsets: one launch
 void launch_finish(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
+// documents with a word of more than MAX_WORD_BYTES bytes end in front of it (core.c:402-407): one workgroup, which
+// returns at once unless k_tiles counted enough tiles without a word start
+void launch_cut(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // one-off at context creation: merge a symbol sequence on the device, return ids
 void launch_bpe_symbols(const DevTables& t, uint32_t* d_syms, int n, int32_t* d_ids_out,
                         int32_t* d_n_out, hipStream_t s);

@@ -251,6 +251,7 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
     if (A.status)
         for (int64_t d = t; d < A.n_docs; d += n_threads) A.status[d] = 0;
     for (int64_t b = t; b < W.n_scan_blocks; b += n_threads) W.scan_state[b] = 0;
+    for (int64_t b = t; b < (A.n_tiles + 31) / 32; b += n_threads) W.noreal_bits[b] = 0;
     if (t >= A.n_tiles) return;
     const int64_t gw = t * TILE_BYTES - LOOKBACK;
     int64_t lo = 0, hi = A.n_docs + 1;  // first d in [0, n_docs] with offsets[d] >= gw
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
     const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
+    uint32_t real_own = 0, halo_real = 1;  // ... without the seams; the same of the halo's 64 positions, one bit per lane
     for (int i = threadIdx.x; i < (dfa::TABLE_BYTES + 256) / 16; i += 64 * WAVES) {
         const uint4 v = T.split_dfa[i];
         reinterpret_cast<uint4*>(&s_m.c)[i] = v;  // table, then byte classes, as uploaded
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             w.a = src[0]; w.b = src[1]; w.c = src[2]; w.d = src[3];
         }
         const uint32_t dbits = (uint32_t)bits64(docm, kb - 8);
-        uint32_t flags;
+        uint32_t flags, flags_real;  // word starts of my 16 positions; the same without the seams
         {
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
@@ -498,6 +500,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
                 flags = classify16_exact_cold(w8, dbits);
             }
+            flags_real = flags;
             if (T.seam_on && !A.word_bits) {
                 // Seams (hutk_internal.h, Tables::seam_hi): where no merge can join the input byte x to the lead byte y of the
                 // three- or four-byte character behind it, the word's encoding is the concatenation of the encodings of
@@ -563,10 +566,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         //   excm   starts of exception words
         const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
         own = flags;                             // starts that are words of this tile
+        real_own = flags_real;
         {
             const int lo = 16 * lane;
             if (lo >= limit) own = 0;
             else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
+            real_own &= own;
+        }
+        // The reference ends a document at a word of more than 262144 bytes (core.c:402-407).  With seams such a word can
+        // be a run of short ones here, so k_cut looks for what every such word leaves behind: at least 272 tiles in a
+        // row without a start of the reference's own.  Normal text never sets a bit.
+        halo_real = (uint32_t)(__ballot(flags_real != 0) >> 60);
+        if (!A.word_bits && !__any(real_own != 0) && lane == 0) {
+            atomicOr(&W.noreal_bits[tile >> 5], 1u << (tile & 31));
+            atomicAdd(&W.counters[6], 1u);
         }
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
         uint32_t nW;
@@ -1235,6 +1248,21 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     wave_sync();
     HUTK_STAMP(7);
 
+    // ... and before the tile's last start of the reference's own, when none follows in the halo: that is where k_cut
+    // cuts a document if the word turns out to be over-long (rare: a word of 64 bytes and more)
+    if (!A.word_bits && halo_real == 0) {
+        const unsigned long long rb = __ballot(real_own != 0);
+        if (rb) {
+            const int lr = 63 - __builtin_clzll(rb);
+            const uint32_t r16 = (uint32_t)__shfl((int)real_own, lr, 64);
+            const int pos = 16 * lr + 31 - __builtin_clz(r16);
+            const uint32_t below = (1u << (pos & 15)) - 1u;
+            uint32_t before = lanepref[lr];
+            before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(livem)[lr] & below);
+            before += extra_ids(lr, wmask16[lr] & below);
+            if (lane == 0) W.tile_lastreal[tile] = (uint32_t)pos | (before << 16);
+        }
+    }
     // ---- 8. ids emitted before each document that starts in this tile ----------
     for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
         const int64_t o = A.offsets[d];
@@ -1796,7 +1824,7 @@ struct EndsWin {
 // start bit of the host's bitmap.  One wavefront; sb / scode / docm are its LDS scratch, cw its window (above).
 // -> end offset; *too_large when the word passes the reference's limit (core.c:402-407).
 __device__ int64_t exc_word_end(const DevTables& T, const BatchArgs& A, int64_t ws, int64_t d, int64_t ds, int64_t de, uint8_t* sb,
-                                uint8_t* scode, uint32_t* docm, int lane, bool* too_large, EndsWin& cw) {
+                                uint8_t* scode, uint32_t* docm, int lane, bool* too_large, EndsWin& cw, bool seams = true) {
     int64_t we = -1;
     *too_large = false;
     if (A.word_bits) {
@@ -1840,7 +1868,7 @@ __device__ int64_t exc_word_end(const DevTables& T, const BatchArgs& A, int64_t 
                 const int64_t q = base + 64 * r + lane;
                 const int wi = 16 + 64 * r + lane;
                 bool st = (q <= de) && word_starts(scode, docm, wi);
-                if (T.seam_on && q < de && sb[wi] >= 0xE0u)  // a seam starts a word as well (k_tiles, phase 3)
+                if (seams && T.seam_on && q < de && sb[wi] >= 0xE0u)  // a seam starts a word as well (k_tiles, phase 3)
                     st = st || !((T.seam_hi[sb[wi - 1]] >> (sb[wi] & 31u)) & 1u);
                 cw.bits[r] = __ballot(st);
             }
@@ -2078,9 +2106,10 @@ __global__ __launch_bounds__(64) void k_bpe_symbols(DevTables T, uint32_t* syms,
 // ------------------------------------------------------------------------
 // k_scan: exclusive scan of tile_count -> tile_base (and the grand total at tile_base[n_tiles]) in ONE launch.  A workgroup
 // scans SCAN_BLOCK tiles, publishes its total at once and its inclusive prefix as soon as it knows it; it adds up its
-// predecessors' totals back to the nearest published prefix (decoupled look-back, as hutk_decode.hip does: workgroups
-// are dispatched in index order, so every predecessor is running or done).  Flag and value share one 64-bit word, so
-// relaxed agent-scope atomics suffice.  A bounded spin turns a broken premise into HUTK_E_DEVICE instead of a hang.
+// predecessors' totals back to the nearest published prefix (decoupled look-back, as hutk_decode.hip does).  A
+// workgroup's place in the chain is a TICKET (counters[7], zeroed by k_pre), not its block index: HIP promises no
+// dispatch order, but every smaller ticket belongs to a workgroup that has started.  Flag and value share one 64-bit
+// word, so relaxed agent-scope atomics suffice.  The spin is bounded all the same (HUTK_E_DEVICE instead of a hang).
 // ------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 2048, SCAN_THREADS = 256, SCAN_PER_THREAD = SCAN_BLOCK / SCAN_THREADS;
 constexpr unsigned long long SC_MASK = 3ull << 62, SC_TOTAL = 1ull << 62, SC_PREFIX = 2ull << 62;
@@ -2100,9 +2129,11 @@ __device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* sh, int t
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan(BatchArgs A, Workspace W) {
     __shared__ int64_t sh[SCAN_THREADS];
-    __shared__ int64_t s_base;
+    __shared__ int64_t s_base, s_ticket;
     const int tid = threadIdx.x;
-    const int64_t blk = blockIdx.x;
+    if (tid == 0) s_ticket = (int64_t)atomicAdd(&W.counters[7], 1u);
+    __syncthreads();
+    const int64_t blk = s_ticket;
     const int64_t base = blk * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
     uint32_t c[SCAN_PER_THREAD];
     int64_t sum = 0;
@@ -2127,7 +2158,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(BatchArgs A, Workspace W)
                 v = SC_PREFIX;  // before block 0: an empty prefix
                 if (p >= 0) v = __hip_atomic_load(&st[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all((v & SC_MASK) != 0)) break;
-                if (++spins > (1u << 22)) {  // seconds: the dispatch-order premise does not hold; fail loudly
+                if (++spins > (1u << 22)) {  // seconds: a predecessor never published (it cannot be waiting for us); fail loudly
                     raise(A.err, HUTK_E_DEVICE);
                     v = SC_PREFIX;
                     break;
@@ -2330,6 +2361,127 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_finish(DevTables T, Batch
     }
 }
 
+// ------------------------------------------------------------------------
+// k_cut: the reference ends a document at a word of more than MAX_WORD_BYTES bytes and says nothing (core.c:402-407 sets
+// error_msg, core.c:503 clears it): the document keeps the ids of the words in front of that word.  Here such a word may
+// have been encoded as a run of shorter ones (seams), so it is found by what it leaves behind whatever it is made of: at
+// least CUT_MIN_RUN tiles in a row without a word start of the reference's own (k_tiles' noreal_bits).  ONE workgroup:
+//   A. its first wavefront walks the runs of such tiles; the word that covers a run starts at the last real start of the
+//      tile in front of it (tile_lastreal: position and ids before it) and ends at the first real start behind the run
+//      (the splitter, without seams).  Over-long: the document is cut at the word's first id.
+//   B. all threads close the gaps in ids_out (segments move left, chunk by chunk, reads before writes) and shift
+//      out_offsets.
+// Returns at once in a batch that has no such run -- every batch of ordinary text.
+// ------------------------------------------------------------------------
+constexpr uint32_t CUT_MIN_RUN = (uint32_t)((MAX_WORD_BYTES + 1 - TILE_BYTES) / TILE_BYTES);  // tiles a word of MAX_WORD_BYTES + 1 bytes covers whole
+constexpr int CUT_THREADS = 1024;
+__global__ __launch_bounds__(CUT_THREADS) void k_cut(DevTables T, BatchArgs A, Workspace W) {
+    if (W.counters[6] < CUT_MIN_RUN) return;
+    __shared__ EndsLds L;
+    __shared__ uint32_t s_n_cuts;
+    __shared__ int32_t s_vals[CUT_THREADS];
+    uint32_t* const cut_doc = W.exc_quad;   // (the exception lists are free by now; a cut needs 272 tiles: they are long enough)
+    uint32_t* const cut_keep = W.exc_wave;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_n_cuts = 0;
+    __syncthreads();
+    if (tid < 64) {
+        const int64_t n_words = (A.n_tiles + 31) / 32;
+        auto bit = [&](int64_t t) -> bool { return t < A.n_tiles && ((W.noreal_bits[t >> 5] >> (t & 31)) & 1u); };
+        int64_t last_doc = -1;
+        uint32_t nc = 0;
+        EndsWin cw;
+        for (int64_t w0 = 0; w0 < n_words; w0 += 64) {
+            const int64_t w = w0 + lane;
+            const uint32_t bits = w < n_words ? W.noreal_bits[w] : 0u;
+            const uint32_t prev = (w > 0 && w <= n_words) ? W.noreal_bits[w - 1] >> 31 : 0u;
+            const uint32_t starts = bits & ~((bits << 1) | prev);  // tiles where a run begins
+            for (unsigned long long bal = __ballot(starts != 0); bal; bal &= bal - 1) {
+                const int l = __builtin_ctzll(bal);
+                for (uint32_t sw = (uint32_t)__shfl((int)starts, l, 64); sw; sw &= sw - 1) {  // (every value below is the same in all lanes)
+                    const int64_t t_first = (w0 + l) * 32 + __builtin_ctz(sw);
+                    int64_t t_end = t_first;  // first tile behind the run
+                    while (bit(t_end)) {
+                        if ((t_end & 31) == 0 && t_end + 32 <= A.n_tiles && W.noreal_bits[t_end >> 5] == 0xFFFFFFFFu) t_end += 32;
+                        else t_end++;
+                    }
+                    if (t_end - t_first < (int64_t)CUT_MIN_RUN || t_first == 0) continue;
+                    const int64_t tp = t_first - 1;  // it has a start of the reference's own, and none in its halo: tile_lastreal is set
+                    const uint32_t lr = W.tile_lastreal[tp];
+                    const int64_t P = tp * TILE_BYTES + (int64_t)(lr & 0xFFFFu);
+                    const int64_t d = doc_of(A, W, P, (uint32_t)tp), ds = A.offsets[d], de = A.offsets[d + 1];
+                    if (d == last_doc) continue;  // cut already, further in front
+                    int64_t E = de;
+                    if (t_end * TILE_BYTES < de) {
+                        bool unused;
+                        E = exc_word_end(T, A, t_end * TILE_BYTES - 1, d, ds, de, L.sb, L.scode, L.docm, lane, &unused, cw, false);
+                        if (E > de) E = de;
+                    }
+                    if (E - P <= MAX_WORD_BYTES) continue;
+                    // ids of the document in front of the word: the dense ones k_tiles counted, and those of the tile's
+                    // exception words in front of P
+                    uint32_t exc_ids = 0;
+                    const uint32_t nexc = W.tile_nexc[tp], first = W.tile_exc_first[tp];
+                    for (uint32_t e = lane; e < nexc; e += 64) {
+                        const uint64_t idx = (uint64_t)first + e;
+                        if ((int64_t)idx >= W.cap_exc) break;
+                        const ExcRec r = W.exc[idx];
+                        if (r.ws < P && r.tok_base >= 0) exc_ids += r.cnt;
+                    }
+                    for (int o = 32; o; o >>= 1) exc_ids += (uint32_t)__shfl_xor((int)exc_ids, o, 64);
+                    const int64_t idpos = W.tile_base[tp] + (int64_t)(lr >> 16) + exc_ids;
+                    const int64_t keep = idpos - A.out_offsets[d];
+                    if (lane == 0) {
+                        cut_doc[nc] = (uint32_t)d;
+                        cut_keep[nc] = (uint32_t)keep;
+                        if (A.status) A.status[d] = HUTK_DOC_WORD_TOO_LARGE;
+                        raise(A.err, HUTK_E_WORD_TOO_LARGE);
+                    }
+                    nc++;
+                    last_doc = d;
+                }
+            }
+        }
+        if (lane == 0) s_n_cuts = nc;
+    }
+    __threadfence();
+    __syncthreads();
+    const uint32_t nc = s_n_cuts;
+    if (nc == 0) return;
+    // B. segment c = the ids between the end of cut document c - 1 and the kept end of cut document c: it moves left by
+    // what the cuts in front of it removed (segment 0 stays); behind the last cut: the rest of the batch
+    int64_t shift = 0, seg_begin = 0, doc_begin = 0;
+    const int64_t total = A.out_offsets[A.n_docs];
+    for (uint32_t c = 0; c <= nc; c++) {
+        int64_t seg_end, doc_end, removed = 0;
+        if (c < nc) {
+            const int64_t d = cut_doc[c], a = A.out_offsets[d], b = A.out_offsets[d + 1];
+            seg_end = a + (int64_t)cut_keep[c];
+            removed = b - seg_end;
+            doc_end = d + 1;  // documents [doc_begin, doc_end) start inside this segment
+            __syncthreads();  // (everybody has read the offsets of document d before they move)
+            seg_end = seg_end < a ? a : seg_end;
+        } else {
+            seg_end = total;
+            doc_end = A.n_docs + 1;
+        }
+        if (shift) {
+            for (int64_t base = seg_begin; base < seg_end; base += CUT_THREADS) {
+                const int64_t i = base + tid;
+                if (i < seg_end) s_vals[tid] = A.ids_out[i];
+                __syncthreads();
+                if (i < seg_end) A.ids_out[i - shift] = s_vals[tid];
+                __syncthreads();
+            }
+            for (int64_t x = doc_begin + tid; x < doc_end; x += CUT_THREADS) A.out_offsets[x] -= shift;
+        }
+        __syncthreads();
+        seg_begin = seg_end + removed;
+        doc_begin = doc_end;
+        shift += removed;
+    }
+}
+
 // k_tail_small: everything behind k_tiles for a batch of a few tiles (a sentence, a handful of documents), where the
 // launches themselves are the cost: ONE wavefront runs the exception stages, the scan and the copy-out one after the
 // other.  Between stages an agent-scope fence makes the wavefront's own global writes visible to its later loads.
@@ -2410,6 +2562,9 @@ void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3((unsigned)w.n_scan_blocks), dim3(SCAN_THREADS), 0, s, a, w);
 }
 int64_t scan_blocks(int64_t n_tiles) { return (n_tiles + SCAN_BLOCK - 1) / SCAN_BLOCK; }
+void launch_cut(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+    hipLaunchKernelGGL(k_cut, dim3(1), dim3(CUT_THREADS), 0, s, t, a, w);
+}
 void launch_finish(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
     const int64_t per_wg = (int64_t)GATHER_TILES * GATHER_WAVES;
     const unsigned g_gather = (unsigned)((a.n_tiles + per_wg - 1) / per_wg);

@@ -137,9 +137,11 @@ int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offset
  * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and
  * the call returns without synchronising; d_err receives the first device-side
  * error code (HUTK_OK when none) and may be NULL.  d_bytes must be 16-byte
- * aligned.  Unlike hutk_encode_batch this form does not trim a document at an
- * over-long word: such a document (d_status[i] = HUTK_DOC_WORD_TOO_LARGE, *d_err =
- * HUTK_E_WORD_TOO_LARGE) holds the ids of all its other words. */
+ * aligned.  A document with a word of more than 262144 bytes ends in front of that
+ * word, as the reference's does (src/core.c:402-407, 503): d_status[i] =
+ * HUTK_DOC_WORD_TOO_LARGE, *d_err = HUTK_E_WORD_TOO_LARGE (a note, not a failure),
+ * and d_out_offsets / d_ids_out hold the shortened document -- the same as
+ * hutk_encode_batch returns. */
 int hutk_encode_batch_device(hutk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets,
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out,
                              int64_t ids_cap, int64_t* d_out_offsets, int32_t* d_status,
