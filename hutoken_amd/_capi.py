@@ -145,14 +145,20 @@ def shim():
         path = _build.LIB_PYSHIM
         if not os.environ.get("HUTOKEN_AMD_NO_SHIM") and not os.environ.get("HUTOKEN_AMD_LIB"):
             try:
-                if not os.path.exists(path):
-                    _build.build_pyshim()
+                try:
+                    _build.build_pyshim(force=bool(os.environ.get("HUTOKEN_AMD_REBUILD")))  # (checks for staleness itself)
+                except Exception:
+                    if not os.path.exists(path):  # no compiler and nothing built earlier
+                        raise
                 load()
                 spec = importlib.util.spec_from_file_location("_hutoken_amd", path)
                 mod = importlib.util.module_from_spec(spec)
                 spec.loader.exec_module(mod)
                 _shim = mod
-            except Exception:  # no compiler, no Python.h: the ctypes path does the same work
+            except Exception as e:  # no compiler, no Python.h: the ctypes path does the same work, 4x slower on lists
+                import warnings
+                warnings.warn("hutoken_amd: the compiled CPython shim is not available (%s); using ctypes" % (e,),
+                              RuntimeWarning, stacklevel=2)
                 _shim = None
     return _shim
 

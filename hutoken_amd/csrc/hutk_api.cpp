@@ -75,7 +75,7 @@ struct hutk_ctx {
     // device tables
     DevBuf<uint64_t> d_pair, d_char;
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
-    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms, d_seam;
+    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms, d_seam, d_item_units;
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<WordSlot> d_word_tab;
@@ -206,6 +206,18 @@ int upload_tables(hutk_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_seam.p, T.seam_hi, sizeof T.seam_hi, hipMemcpyHostToDevice));
     D.seam_hi = c->d_seam.p;
     D.seam_on = T.seam_on && !(getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ? 1 : 0;
+    {   // multi bits [8], unit offsets [257], units: one allocation
+        std::vector<uint32_t> iu(T.multi_bits, T.multi_bits + 8);
+        iu.insert(iu.end(), T.item_units_off, T.item_units_off + 257);
+        iu.insert(iu.end(), T.item_units.begin(), T.item_units.end());
+        HIP_TRY(c->d_item_units.reserve(iu.size()));
+        HIP_TRY(hipMemcpy(c->d_item_units.p, iu.data(), iu.size() * 4, hipMemcpyHostToDevice));
+        D.multi_bits = c->d_item_units.p;
+        D.item_units_off = c->d_item_units.p + 8;
+        D.item_units = c->d_item_units.p + 8 + 257;
+        D.has_multi = T.has_multi ? 1 : 0;
+        D.unit_scale = (int32_t)T.max_units_per_item;
+    }
     D.item_sym = c->d_item_sym.p;
     D.item_direct = c->d_item_direct.p;
     D.char_slots = c->d_char.p;
@@ -304,7 +316,7 @@ int pad_per_doc(const hutk_ctx* c) {
 int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_tiles, Workspace& W) {
     const int64_t pad = pad_per_doc(c);
     const size_t run_elems = (size_t)(n_tiles * RUN_STRIDE + 512);
-    const size_t exc_elems = (size_t)(n_bytes + pad * (n_docs + 2) + 512);
+    const size_t exc_elems = (size_t)(n_bytes * (int64_t)c->tab.max_units_per_item + pad * (n_docs + 2) + 512);
     HIP_TRY(c->w_run.reserve(run_elems));
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));
     HIP_TRY(c->w_exc_sym.reserve(exc_elems));
@@ -314,7 +326,9 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     HIP_TRY(c->w_counters.reserve(8));
     HIP_TRY(c->w_err.reserve(1));
-    const int64_t cap_exc = n_bytes / LANE_MAX_UNITS + n_docs + n_tiles + 64;
+    // exception words: longer than a lane takes (more than LANE_MAX_UNITS bytes), first of their document, or cut off by
+    // a tile's budget -- unless items of several units make ANY word one (then: at most a word per byte)
+    const int64_t cap_exc = (c->tab.has_multi ? n_bytes : n_bytes / LANE_MAX_UNITS) + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_quad.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_wave.reserve((size_t)cap_exc));
@@ -360,7 +374,7 @@ void destroy(hutk_ctx* c) {
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
-        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release(); c->d_item_units.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
@@ -400,7 +414,7 @@ int build_word_table(hutk_ctx* c) {
     if (!n) return HUTK_OK;
     std::vector<int64_t> offs(n + 1), oo(n + 1);
     for (size_t i = 0; i <= n; i++) offs[i] = T.cand_off[i];
-    std::vector<int32_t> ids(T.cand_bytes.size() + (size_t)pad_per_doc(c) * n + 1);
+    std::vector<int32_t> ids((size_t)hutk_ids_capacity(c, (int64_t)T.cand_bytes.size(), (int64_t)n));
     // candidates are encoded one per document, as words that are NOT first in their document: no prefix
     const int had_prefix = c->dt.has_prefix;
     c->dt.has_prefix = 0;
@@ -546,15 +560,15 @@ int hutk_ctx_add_device(hutk_ctx* c, int device) {
     hutk_ctx* p = new (std::nothrow) hutk_ctx();
     if (!p) return set_err(HUTK_E_MEMORY, "out of memory");
     p->tab = c->tab;  // the host tables as loaded: same files, same ids
-    p->pattern = c->pattern;
     p->timing = false;
-    const int rc = attach_device(p, device);
+    const int rc = attach_device(p, device);  // (builds the whole-word table with the hand-written splitter, like the first device)
     if (rc) {
         std::string keep = g_err;
         destroy(p);
         g_err = keep;
         return rc;
     }
+    p->pattern = c->pattern;
     c->peers.push_back(p);
     c->peer_ids.emplace_back();
     return HUTK_OK;
@@ -566,7 +580,8 @@ void hutk_ctx_destroy(hutk_ctx* ctx) { destroy(ctx); }
 
 int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs) {
     if (!ctx) return 0;
-    return n_bytes + (int64_t)pad_per_doc(ctx) * n_docs + 1;
+    // at most one id per unit: a unit per input byte, or max_units_per_item where a replacement has several (SURVEY 8 b)
+    return n_bytes * (int64_t)ctx->tab.max_units_per_item + (int64_t)pad_per_doc(ctx) * n_docs + 1;
 }
 
 int64_t hutk_vocab_size(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_keys : 0; }
@@ -806,9 +821,19 @@ static int encode_batch_regex(hutk_ctx* c, const uint8_t* bytes, const int64_t* 
 
 int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
+    // (encode calls on other threads read the pattern under the context's mutex, each peer under its own)
+    auto assign = [&](const char* v) {
+        {
+            std::lock_guard<std::recursive_mutex> lock(c->mu);
+            c->pattern = v;
+        }
+        for (hutk_ctx* p : c->peers) {
+            std::lock_guard<std::recursive_mutex> lock(p->mu);
+            p->pattern = v;
+        }
+    };
     if (!pattern) {
-        c->pattern.clear();
-        for (hutk_ctx* p : c->peers) p->pattern.clear();
+        assign("");
         return HUTK_OK;
     }
     if (c->tab.has_prefix)
@@ -817,18 +842,18 @@ int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
     if (!*pattern || regcomp(&re, pattern, REG_EXTENDED) != 0)
         return set_err(HUTK_E_VALUE, "Regex could not be compiled.");  // core.c:352-358
     regfree(&re);
-    c->pattern = pattern;
-    for (hutk_ctx* p : c->peers) p->pattern = pattern;
+    assign(pattern);
     return HUTK_OK;
 }
 
 // one context, one device
 static int encode_batch_one(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                             int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
+    if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     std::lock_guard<std::recursive_mutex> lock(c->mu);  // (the staging buffers are the context's too)
-    if (c && !c->host_only && !c->pattern.empty())
+    if (!c->host_only && !c->pattern.empty())
         return encode_batch_regex(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
-    if (c && !c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
+    if (!c->host_only && offsets && out_offsets && n_docs > 0 && offsets[0] == 0 &&
         offsets[n_docs] >= PIPE_MIN_BYTES && !getenv("HUTK_NO_PIPELINE")) {
         return encode_batch_pipelined(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status);
     }
@@ -975,6 +1000,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
     D.first_bits = c->dw_first.p;
     D.tile_state = c->dw_state.p;
     D.tile_first_doc = c->dw_tfd.p;
+    D.help_after = getenv("HUTK_DEC_HELP_AFTER") ? (uint32_t)atol(getenv("HUTK_DEC_HELP_AFTER")) : (1u << 14);  // (0: tests of the fallback)
     HIP_TRY(hipMemsetAsync(D.err, 0, 4, s));
     const bool strip = c->dec.sent != nullptr;  // the first-token bitmap is only needed to strip a prefix
     if (strip) HIP_TRY(hipMemsetAsync(D.first_bits, 0, (size_t)(n_ids / 32 + 4) * 4, s));
@@ -985,7 +1011,7 @@ int hutk_decode_batch_device(hutk_ctx* c, const int32_t* d_ids, const int64_t* d
         return HUTK_OK;
     }
     if (strip) launch_dec_mark(D, s);
-    HIP_TRY(hipMemsetAsync(D.tile_state, 0, (size_t)(n_tiles + 1) * 8, s));  // the tiles' states and the ticket counter behind them
+    HIP_TRY(hipMemsetAsync(D.tile_state, 0, (size_t)n_tiles * 8, s));
     launch_dec(c->dec, D, s);
     HIP_TRY(hipGetLastError());
     return HUTK_OK;

@@ -88,13 +88,26 @@ __device__ __forceinline__ uint2 dec_entry(const DecTables& T, const DecArgs& D,
 }
 __device__ __forceinline__ uint32_t dec_len_of(uint2 e) { return (e.x & DEC_TAG_LONG) ? e.x >> 8 : (e.x & 0xFFu); }
 
-// One tile of DEC_TILE ids.  The look-back below waits for the tiles in front of this one, so which workgroup takes
-// which tile must not depend on the order in which the hardware starts workgroups (HIP promises none): k_dec_tiles hands
-// tiles out by ticket.
+// Bytes of tile p's text, computed by ONE lane: what a workgroup falls back on when a tile in front of its own has not
+// published its total for a long time (see the look-back in k_dec_tiles).  Errors are reported by the tile's own
+// workgroup as well; reporting them twice is harmless.
+__device__ __forceinline__ uint64_t dec_tile_total(const DecTables& T, const DecArgs& D, int64_t p) {
+    const int64_t a = p * DEC_TILE, b = (a + DEC_TILE < D.n_ids) ? a + DEC_TILE : D.n_ids;
+    uint64_t sum = 0;
+    for (int64_t i = a; i < b; i++) {
+        const bool first = D.first_bits && ((D.first_bits[i >> 5] >> (i & 31)) & 1u);
+        sum += dec_len_of(dec_entry(T, D, i, D.ids[i], first));
+    }
+    return sum;
+}
+
 template <bool WRITE>
-__device__ __forceinline__ void dec_one_tile(const DecTables& T, const DecArgs& D, const int64_t tile, uint32_t* s_part,
-                                             uint16_t* s_pref, uint8_t* s_text, int64_t& s_g0) {
+__global__ __launch_bounds__(DEC_THREADS) __attribute__((amdgpu_waves_per_eu(5))) void k_dec_tiles(DecTables T, DecArgs D) {  // (96 VGPRs: with the look-back's fallback inlined the compiler takes 98 and loses a wavefront per SIMD)
+    __shared__ uint32_t s_part[DEC_THREADS / 64];
+    __shared__ uint16_t s_pref[DEC_TILE];  // bytes of the tile before each of its tokens
+    __shared__ __attribute__((aligned(16))) uint8_t s_text[WRITE ? DEC_LDS_BYTES + 16 : 16];
     const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * DEC_TILE + (int64_t)tid * DEC_PER_THREAD;
     uint2 ent[DEC_PER_THREAD];
     uint32_t len[DEC_PER_THREAD];
@@ -137,9 +150,12 @@ __device__ __forceinline__ void dec_one_tile(const DecTables& T, const DecArgs& 
     uint32_t before = wave_base + incl - mine;
     // Byte offset of the tile's text = total of all earlier tiles, by decoupled look-back: every tile
     // publishes its own total at once and its inclusive prefix as soon as it knows it; a tile adds up the totals
-    // of its predecessors back to the nearest published prefix (tiles are handed out by ticket, so every
-    // predecessor is running or done whatever order the workgroups start in).  One pass over the ids instead of
-    // sizes + scan + write.
+    // of its predecessors back to the nearest published prefix.  One pass over the ids instead of sizes + scan +
+    // write.  Workgroups start in index order on this hardware, so a predecessor is running or done and the wait
+    // is short; HIP promises no such order, though, and nothing here depends on it: a workgroup that has waited
+    // for a predecessor for milliseconds adds that tile's bytes up ITSELF (dec_tile_total) and goes on, so every
+    // look-back ends whatever the dispatch order -- slowly in that case, but without a hang or a wrong offset.
+    // (Tiles handed out by ticket instead -- a returning atomic per workgroup -- cost 12 % of the kernel.)
     // Flag and value share one 64-bit word, so relaxed agent-scope atomics suffice: nothing else is
     // communicated, and acquire/release at agent scope would write back / invalidate the XCD's L2 per tile.
     unsigned long long* st = D.tile_state;
@@ -196,6 +212,7 @@ __device__ __forceinline__ void dec_one_tile(const DecTables& T, const DecArgs& 
             }
         }
     }
+    __shared__ int64_t s_g0;
     if (tid < 64) {  // wavefront 0 looks back
         const int lane = tid;
         int64_t excl = 0;
@@ -216,10 +233,11 @@ __device__ __forceinline__ void dec_one_tile(const DecTables& T, const DecArgs& 
 #pragma unroll
                     for (int j = 0; j < DEC_LOOK; j++) ready = ready && (v[j] & DEC_ST_MASK) != 0;
                     if (__all(ready)) break;
-                    if (++spins > (1u << 22)) {  // seconds: a predecessor never published (it cannot be waiting for us);
-                        dec_raise(D.err, HUTK_E_DEVICE);  // fail loudly instead of hanging the GPU
+                    if (++spins > D.help_after) {  // (tens of milliseconds by default) not dispatched yet, perhaps never before we leave
 #pragma unroll
-                        for (int j = 0; j < DEC_LOOK; j++) v[j] = DEC_ST_PREFIX;
+                        for (int j = 0; j < DEC_LOOK; j++)
+                            if ((v[j] & DEC_ST_MASK) == 0)
+                                v[j] = DEC_ST_TOTAL | (unsigned long long)dec_tile_total(T, D, hi - lane - 64 * j);
                         break;
                     }
                 }
@@ -297,25 +315,6 @@ __device__ __forceinline__ void dec_one_tile(const DecTables& T, const DecArgs& 
     }
 }
 
-// Tiles by ticket, DEC_GROUP consecutive ones per ticket (a returning atomic per tile on one address would pace the
-// launch: ~88 per microsecond, MI355X_MICROARCH.md "dequeue", against ~60 tiles per microsecond of this kernel).  A
-// ticket's tiles are behind every tile of every smaller ticket, and those tickets' workgroups have started.
-constexpr int DEC_GROUP = 4;
-template <bool WRITE>
-__global__ __launch_bounds__(DEC_THREADS) void k_dec_tiles(DecTables T, DecArgs D) {
-    __shared__ uint32_t s_part[DEC_THREADS / 64];
-    __shared__ uint16_t s_pref[DEC_TILE];  // bytes of the tile before each of its tokens
-    __shared__ __attribute__((aligned(16))) uint8_t s_text[WRITE ? DEC_LDS_BYTES + 16 : 16];
-    __shared__ int64_t s_g0, s_ticket;
-    if (threadIdx.x == 0) s_ticket = (int64_t)atomicAdd(&D.tile_state[D.n_tiles], 1ull);  // (zeroed with the states)
-    __syncthreads();
-    const int64_t first = s_ticket * DEC_GROUP;
-    for (int64_t tile = first; tile < first + DEC_GROUP && tile < D.n_tiles; tile++) {
-        dec_one_tile<WRITE>(T, D, tile, s_part, s_pref, s_text, s_g0);
-        __syncthreads();  // the shared arrays are the next tile's
-    }
-}
-
 __global__ void k_dec_tail(DecArgs D) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > D.n_docs) return;
@@ -332,9 +331,8 @@ void launch_dec_mark(const DecArgs& d, hipStream_t s) {
 }
 void launch_dec(const DecTables& t, const DecArgs& d, hipStream_t s) {
     hipLaunchKernelGGL(k_dec_pre, dim3((unsigned)((d.n_tiles + 255) / 256)), dim3(256), 0, s, d);
-    const dim3 g((unsigned)((d.n_tiles + DEC_GROUP - 1) / DEC_GROUP));
-    if (d.bytes_out) hipLaunchKernelGGL(k_dec_tiles<true>, g, dim3(DEC_THREADS), 0, s, t, d);
-    else hipLaunchKernelGGL(k_dec_tiles<false>, g, dim3(DEC_THREADS), 0, s, t, d);
+    if (d.bytes_out) hipLaunchKernelGGL(k_dec_tiles<true>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
+    else hipLaunchKernelGGL(k_dec_tiles<false>, dim3((unsigned)d.n_tiles), dim3(DEC_THREADS), 0, s, t, d);
     hipLaunchKernelGGL(k_dec_tail, dim3((unsigned)((d.n_docs + 1 + 255) / 256)), dim3(256), 0, s, d);
 }
 

@@ -72,6 +72,13 @@ struct DevTables {
     // of its own starts at y (k_tiles, exc_word_end).  seam_on == 0: never split (regex path, HUTK_NO_SEAM=1)
     const uint32_t* seam_hi;
     int32_t seam_on;
+    // items with a replacement of several units, or of none (Tables::multi_bits): bit b of multi_bits[8]; the units of
+    // item b are item_units[item_units_off[b] .. item_units_off[b + 1]).  has_multi == 0: every item is one unit.
+    // unit_scale = most units one input item can become: exception words own unit_scale slots per byte.
+    const uint32_t* multi_bits;
+    const uint32_t* item_units_off;
+    const uint32_t* item_units;
+    int32_t has_multi, unit_scale;
 };
 
 // one word the tile kernel hands to the exception kernel
@@ -152,6 +159,7 @@ struct DecArgs {
     uint32_t* first_bits;       // [n_ids / 32 + 2] bit i: token i is the first of a document
     unsigned long long* tile_state;  // [n_tiles] decoupled look-back: flag (2 bits) | total or inclusive prefix
     int64_t* tile_first_doc;    // [n_tiles] first document whose first token is at or after the tile's
+    uint32_t help_after;        // look-back: polls of a predecessor's state before a tile adds that tile's bytes up itself
 };
 int64_t dec_tile_ids();
 void launch_dec_mark(const DecArgs& d, hipStream_t s);

@@ -143,6 +143,15 @@ struct Tables {
     //                      the lead byte has a replacement or is ASCII
     uint32_t item_sym[256];
     uint8_t item_direct[256];  // 1: item_sym valid for this (lead) byte
+    // A special-character replacement of several units (or of none) makes its item "multi": bit b of multi_bits; the
+    // units of every item are item_units[item_units_off[b] .. item_units_off[b + 1]) (one entry, item_sym[b], for an
+    // ordinary item).  A word with a multi item is an exception word: d_exc expands it.  max_units_per_item scales the
+    // id capacity and the exception arrays (SURVEY section 8 b).
+    uint32_t multi_bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t item_units_off[257] = {0};
+    std::vector<uint32_t> item_units;
+    uint32_t max_units_per_item = 1;
+    bool has_multi = false;
     // non-byte mode: multi-byte character (packed little-endian) -> symbol
     std::vector<uint64_t> char_slots;  // [packed:32][sym:32], SLOT_EMPTY
     uint32_t char_mask = 0;

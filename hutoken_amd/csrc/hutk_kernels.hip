@@ -364,6 +364,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     } s_m;
     static_assert(M_ARENA >= 2 * LANE_MAX_UNITS, "arena size");
     uint32_t* const pool = s_m.g.pool;
+#if HUTK_LAB_LDS_PAD
+    __shared__ uint32_t s_lab_pad[HUTK_LAB_LDS_PAD / 4];  // MEASUREMENT ONLY
+    if (A.n_docs < 0) s_lab_pad[threadIdx.x] = 1;
+#endif
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b works on
@@ -609,6 +613,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const bool gap = A.gap_bits && ((A.gap_bits[(t0 + ws) >> 5] >> ((t0 + ws) & 31)) & 1u);
                 const bool pfx = !gap && T.has_prefix && docfirst && b0 != ' ';
                 bool exc = !gap && (!known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst));
+                if (T.has_multi && !gap && !exc) {
+                    // an item whose replacement has several units, or none (pretokenizer.c:102-168 emits any string): the
+                    // word's units are not one per item; the exception kernels expand it (uniform branch, rare vocabularies)
+                    bool m = false;
+                    for (int i = 0; i < nb; i++) {
+                        const uint32_t b = sb[ws + LOOKBACK + i];
+                        if (BYTE_MODE || !is_cont(b)) m = m || ((T.multi_bits[b >> 5] >> (b & 31u)) & 1u);
+                    }
+                    exc = m;
+                }
                 if (!BYTE_MODE && !exc && T.has_prefix && docfirst && !pfx)  // prefix-alone ids go in front
                     exc = atomicAdd(&s_extra, (uint32_t)T.n_prefix_alone) + T.n_prefix_alone > (uint32_t)RUN_EXTRA;
                 // Every global load of this round is issued here, unconditionally and together, so that the round
@@ -1492,6 +1506,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
         ExcRec rec{};
         if (have) rec = W.exc[idx];
         have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
+        have = have && !T.has_multi;  // (items of several units: every exception word goes to d_exc, which expands them)
         int64_t d = 0, gbase = 0;
         int n = 0, na = 0;
         uint64_t live = 0, cand = 0;
@@ -1504,7 +1519,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
             const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
-            gbase = ws + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
             if (kp + nb > MEDIUM_UNITS) {
                 have = false;  // k_exc
             } else {
@@ -1633,7 +1648,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
         // A word of known length that is not taken here (prefix units make it longer than MEDIUM_UNITS) goes straight on
         // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
         const bool leave = !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0;
-        const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym;  // (prefix units + 63 bytes <= QUAD_UNITS)
+        const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS)
         const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
         if (bq | bw) {
             uint32_t aq = 0, aw = 0;
@@ -1701,7 +1716,7 @@ __device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& 
             const bool alone = with_prefix && A.bytes[ws] == ' ';
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
-            gbase = ws + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
             {
                 n = kp + rec.len;  // <= QUAD_UNITS: the ends pass checked
                 for (int i = l; i < kp; i += 16) Sg[i] = T.prefix_syms[i];
@@ -1937,7 +1952,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
                 continue;
             }
             const bool pfx_units = T.has_prefix && ws == ds && A.bytes[ws] != ' ';
-            const bool quad = T.is_byte_encoder && T.rank_is_sym && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
+            const bool quad = T.is_byte_encoder && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
             if (lane == 0) {
                 W.exc[idx].len = (int32_t)nb;
                 if (quad) lq[nq] = idx; else lw[nw] = idx;
@@ -1986,11 +2001,25 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         const bool with_prefix = T.has_prefix && docfirst;
         const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
         const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
-        const int64_t gbase = ws + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+        const int64_t gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);  // unit_scale slots per byte: room for an expanded word
 
         // unit count
         int64_t n_units;
-        if (T.is_byte_encoder) {
+        // units of the item that starts at byte i (0 inside a character): one, unless its replacement has several or none
+        auto item_units = [&](int64_t i, uint32_t b) -> uint32_t {
+            if (i >= nb || (!T.is_byte_encoder && is_cont(b))) return 0u;
+            return (T.is_byte_encoder || T.item_direct[b]) ? T.item_units_off[b + 1] - T.item_units_off[b] : 1u;
+        };
+        if (T.has_multi) {
+            int64_t cnt = 0;
+            for (int64_t i0 = 0; i0 < nb; i0 += 64) {
+                const int64_t i = i0 + lane;
+                uint32_t c = item_units(i, i < nb ? A.bytes[ws + i] : 0x80u), tot;
+                (void)wave_excl_scan(c, lane, &tot);
+                cnt += tot;
+            }
+            n_units = cnt;
+        } else if (T.is_byte_encoder) {
             n_units = nb;
         } else {
             int64_t cnt = 0;
@@ -2010,7 +2039,38 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         for (int i = lane; i < kp; i += 64) {
             if (in_lds) Sl_a.set(i, T.prefix_syms[i]); else Sg_a.set(i, T.prefix_syms[i]);
         }
-        if (T.is_byte_encoder) {
+        if (T.has_multi) {
+            // expansion: every item writes its units behind those of the items in front of it
+            int64_t ubase = kp;
+            for (int64_t i0 = 0; i0 < nb; i0 += 64) {
+                const int64_t i = i0 + lane;
+                const uint32_t b = i < nb ? A.bytes[ws + i] : 0x80u;
+                const uint32_t c = item_units(i, b);
+                uint32_t tot;
+                const int64_t u = ubase + wave_excl_scan(c, lane, &tot);
+                if (i < nb && (T.is_byte_encoder || T.item_direct[b])) {
+                    const uint32_t* units = T.item_units + T.item_units_off[b];
+                    for (uint32_t k = 0; k < c; k++) {
+                        if (in_lds) Sl_a.set(u + k, units[k]); else Sg_a.set(u + k, units[k]);
+                    }
+                } else if (c) {  // a multi-byte character without replacement
+                    const int L = (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                    uint32_t sym = SYM_UNK;
+                    if (L == 1 || b >= 0xF8u || i + L > nb) {
+                        raise(A.err, HUTK_E_INVALID_UTF8);
+                    } else {
+                        uint32_t packed = b | ((uint32_t)A.bytes[ws + i + 1] << 8);
+                        if (L > 2) packed |= (uint32_t)A.bytes[ws + i + 2] << 16;
+                        if (L > 3) packed |= (uint32_t)A.bytes[ws + i + 3] << 24;
+                        sym = char_lookup(T, packed);
+                    }
+                    if (in_lds) Sl_a.set(u, sym); else Sg_a.set(u, sym);
+                } else if (i == 0 && i < nb) {
+                    raise(A.err, HUTK_E_INVALID_UTF8);  // a word cannot begin inside a character
+                }
+                ubase += tot;
+            }
+        } else if (T.is_byte_encoder) {
             for (int64_t i = lane; i < nb; i += 64) {
                 const uint32_t sym = T.item_sym[A.bytes[ws + i]];
                 if (in_lds) Sl_a.set(kp + i, sym); else Sg_a.set(kp + i, sym);
@@ -2261,6 +2321,7 @@ __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs
         if (tid == 0) raise(A.err, HUTK_E_CAPACITY);
         continue;
     }
+    if ((int64_t)W.tile_exc_first[tile] + (int64_t)nexc > W.cap_exc) continue;  // (k_tiles has raised HUTK_E_MEMORY: records are missing)
     wave_sync();  // the LDS arrays are reused from the previous tile (one wavefront runs this: LDS order is enough)
     ExcRec* recs = W.exc + W.tile_exc_first[tile];
     // positions and id counts of the tile's exception words, one record per lane (all loads in flight
@@ -2391,16 +2452,19 @@ __global__ __launch_bounds__(CUT_THREADS) void k_cut(DevTables T, BatchArgs A, W
         int64_t last_doc = -1;
         uint32_t nc = 0;
         EndsWin cw;
+        // A run of CUT_MIN_RUN tiles holds whole words of ones; text that sets a bit here and there (paragraphs of CJK
+        // characters) has none, and is done with after this scan.  A run is taken up at its first whole word.
         for (int64_t w0 = 0; w0 < n_words; w0 += 64) {
             const int64_t w = w0 + lane;
             const uint32_t bits = w < n_words ? W.noreal_bits[w] : 0u;
-            const uint32_t prev = (w > 0 && w <= n_words) ? W.noreal_bits[w - 1] >> 31 : 0u;
-            const uint32_t starts = bits & ~((bits << 1) | prev);  // tiles where a run begins
-            for (unsigned long long bal = __ballot(starts != 0); bal; bal &= bal - 1) {
+            const uint32_t prev = (w > 0 && w <= n_words) ? W.noreal_bits[w - 1] : 0u;
+            const bool head = bits == 0xFFFFFFFFu && prev != 0xFFFFFFFFu;
+            for (unsigned long long bal = __ballot(head); bal; bal &= bal - 1) {
                 const int l = __builtin_ctzll(bal);
-                for (uint32_t sw = (uint32_t)__shfl((int)starts, l, 64); sw; sw &= sw - 1) {  // (every value below is the same in all lanes)
-                    const int64_t t_first = (w0 + l) * 32 + __builtin_ctz(sw);
-                    int64_t t_end = t_first;  // first tile behind the run
+                {   // (every value below is the same in all lanes)
+                    const uint32_t pv = (uint32_t)__shfl((int)prev, l, 64);
+                    const int64_t t_first = (w0 + l) * 32 - __builtin_clz(~pv);  // the ones at the top of the word in front belong to the run
+                    int64_t t_end = (w0 + l) * 32;  // first tile behind the run
                     while (bit(t_end)) {
                         if ((t_end & 31) == 0 && t_end + 32 <= A.n_tiles && W.noreal_bits[t_end >> 5] == 0xFFFFFFFFu) t_end += 32;
                         else t_end++;

@@ -22,6 +22,9 @@
 #ifndef HUTK_MERGE_STAMPS
 #define HUTK_MERGE_STAMPS 0
 #endif
+#ifndef HUTK_LAB_LDS_PAD
+#define HUTK_LAB_LDS_PAD 0  // bytes of unused LDS per workgroup of k_tiles: fewer resident workgroups (is the kernel bound by latency or by issue?)
+#endif
 #define HUTK_STAMP_AT(k)                                                       \
     do {                                                                       \
         if (W.prof && lane == 0) W.prof[tile * N_PHASE + (k)] = clock64();     \

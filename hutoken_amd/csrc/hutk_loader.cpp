@@ -201,6 +201,23 @@ uint32_t pow2_at_least(uint64_t n) {
 }
 
 
+// item -> its units (Tables::item_units): one unit = item_sym[b] unless the replacement has several, or none
+void finish_item_units(Tables& T, const std::vector<uint32_t> multi[256]) {
+    T.item_units.clear();
+    T.max_units_per_item = 1;
+    for (int b = 0; b < 256; b++) {
+        T.item_units_off[b] = (uint32_t)T.item_units.size();
+        if ((T.multi_bits[b >> 5] >> (b & 31)) & 1u) {
+            T.item_units.insert(T.item_units.end(), multi[b].begin(), multi[b].end());
+            T.max_units_per_item = std::max<uint32_t>(T.max_units_per_item, (uint32_t)multi[b].size());
+            T.has_multi = true;
+        } else {
+            T.item_units.push_back(T.item_sym[b]);
+        }
+    }
+    T.item_units_off[256] = (uint32_t)T.item_units.size();
+}
+
 // (left, right) -> merged entries into the bucketed pair table (hutk_internal.h)
 LoadError finish_pair_table(Tables& T, const std::vector<uint64_t>& entries_in) {
     T.n_sym = (uint32_t)T.sym_id.size();
@@ -590,6 +607,7 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
     // ---- items -> initial symbols: a replacement must be ONE character (the unit rule here is the UTF-8
     // length alone, core.c:460-474, so a longer replacement is several units per input item) ----
     std::string item_str[256];
+    std::vector<uint32_t> multi[256];
     for (int b = 1; b < 256; b++) {
         T.item_sym[b] = SYM_UNK;
         T.item_direct[b] = 0;
@@ -598,9 +616,22 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
         std::string s;
         if (has_special[b]) {
             s = special[b];
-            if (!single_char(s))
-                return fail(HUTK_E_UNSUPPORTED,
-                            "with a merges file every special-character replacement has to be one character");
+            if (!single_char(s)) {
+                // several characters (Llama-style "<0x0A>"): on this path the units are the characters, each looked up in
+                // the vocabulary (core.c:460-474 splits by UTF-8 length only)
+                for (size_t i = 0; i < s.size();) {
+                    const size_t cl = (size_t)lead_len((unsigned char)s[i]);
+                    if (i + cl > s.size())
+                        return fail(HUTK_E_UNSUPPORTED, "special-character replacement is not a whole number of units");
+                    multi[b].push_back(unit_symbol(s.substr(i, cl)));
+                    i += cl;
+                }
+                item_str[b] = s;
+                T.item_sym[b] = multi[b].empty() ? SYM_UNK : multi[b][0];
+                T.item_direct[b] = 1;
+                T.multi_bits[b >> 5] |= 1u << (b & 31);
+                continue;
+            }
         } else if (is_byte_encoder && b >= 0x80) {
             s.push_back((char)(0xC0 | (b >> 6)));
             s.push_back((char)(0x80 | (b & 0x3F)));
@@ -615,6 +646,7 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
     }
     T.item_sym[0] = SYM_UNK;
     T.item_direct[0] = 1;
+    finish_item_units(T, multi);
 
     // ---- prefix ----
     if (prefix && prefix[0]) {
@@ -686,7 +718,7 @@ LoadError build_id_tables(const std::unordered_map<std::string, int32_t>& vocab,
         std::unordered_map<std::string, int> byte_of_unit;
         bool ambiguous = false;
         for (int b = 1; b < 256; b++) {
-            if (!T.item_direct[b]) continue;
+            if (!T.item_direct[b] || ((T.multi_bits[b >> 5] >> (b & 31)) & 1u)) continue;
             auto ins = byte_of_unit.emplace(item_str[b], b);
             if (!ins.second) ambiguous = true;
         }
@@ -900,6 +932,7 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
 
     // ---- items -> initial symbols ----
     std::vector<std::string> units;
+    std::vector<uint32_t> multi[256];
     const bool raw_lt_possible = !has_special[(unsigned char)'<'];
     for (int b = 1; b < 256; b++) {
         T.item_sym[b] = SYM_UNK;
@@ -919,9 +952,17 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
                 return fail(HUTK_E_UNSUPPORTED,
                             "special-character replacement starting with '0' could complete a "
                             "\"<0x..>\" literal begun by a raw '<'");
-            if (units.size() != 1)
-                return fail(HUTK_E_UNSUPPORTED,
-                            "special-character replacement with more than one unit");
+            if (units.size() != 1) {
+                // a replacement of several units (pretokenizer.c:102-168 emits any string; tests/test_pretokenizer.c:38-41
+                // 'a' -> "Alpha"), or of none: the item's units are listed apart, and a word that holds such an item is
+                // encoded by the exception kernels, which expand it (k_tiles, d_exc)
+                multi[b].reserve(units.size());
+                for (auto& u : units) multi[b].push_back(pseudo(u));
+                T.item_sym[b] = units.empty() ? SYM_UNK : multi[b][0];
+                T.item_direct[b] = 1;
+                T.multi_bits[b >> 5] |= 1u << (b & 31);
+                continue;
+            }
         } else if (is_byte_encoder && b >= 0x80) {  // pretokenizer.c:138-141
             s.push_back((char)(0xC0 | (b >> 6)));
             s.push_back((char)(0x80 | (b & 0x3F)));
@@ -935,6 +976,7 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
         T.item_sym[b] = pseudo(s);
         T.item_direct[b] = 1;
     }
+    finish_item_units(T, multi);
     T.item_sym[0] = SYM_UNK;
     T.item_direct[0] = 1;
 
@@ -1011,6 +1053,7 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
         bool ambiguous = false;
         for (int b = 1; b < 256; b++) {
             if (!T.item_direct[b]) continue;  // lead byte of a character looked up in the char table
+            if ((T.multi_bits[b >> 5] >> (b & 31)) & 1u) continue;  // (its words never reach the table)
             auto ins = byte_of_sym.emplace(T.item_sym[b], b);
             if (!ins.second) ambiguous = true;
         }

@@ -24,7 +24,26 @@
 
 #include "hutoken_amd.h"
 
-static hutk_ctx* g_ctx = NULL;       /* process-global like global_encode_context (lib.c:73-74) */
+/* Process-global like global_encode_context (lib.c:73-74).  The calls below release the GIL around the C ABI, so another
+ * thread may re-initialise meanwhile: a context is destroyed only when the last call that uses it has returned (the
+ * reference leaks its old contexts instead, lib.c:129-155).  Every field is touched with the GIL held. */
+typedef struct ctx_box {
+    hutk_ctx* ctx;
+    long users;   /* calls in flight on this context */
+    int retired;  /* initialize() has replaced it */
+} ctx_box;
+static ctx_box* g_box = NULL;
+static ctx_box* box_acquire(void) {
+    ctx_box* b = g_box;
+    if (b) b->users++;
+    return b;
+}
+static void box_release(ctx_box* b) {
+    if (--b->users == 0 && b->retired) {
+        hutk_ctx_destroy(b->ctx);
+        free(b);
+    }
+}
 static PyObject** g_int_cache = NULL; /* [g_cache_n] ints of the ids 0 .. vocabulary size - 1, NULL until first used */
 static int64_t g_cache_n = 0;
 
@@ -113,39 +132,44 @@ static PyObject* p_initialize(PyObject* self, PyObject* args, PyObject* kwargs) 
     }
     Py_END_ALLOW_THREADS
     if (rc != HUTK_OK) return raise_code(rc);
-    hutk_ctx* old = g_ctx;
-    g_ctx = ctx;
+    ctx_box* box = calloc(1, sizeof *box);
+    if (!box) {
+        hutk_ctx_destroy(ctx);
+        return PyErr_NoMemory();
+    }
+    box->ctx = ctx;
+    ctx_box* old = g_box;
+    g_box = box;
     drop_cache();
     g_cache_n = hutk_vocab_size(ctx) + 1024;  /* ids usually are 0 .. size - 1; anything else gets its own object */
     if (g_cache_n > (1 << 22)) g_cache_n = 1 << 22;
     g_int_cache = calloc((size_t)g_cache_n, sizeof(PyObject*));
     if (!g_int_cache) g_cache_n = 0;
-    if (old) hutk_ctx_destroy(old);  /* (the reference leaks its old contexts, lib.c:129-155) */
+    if (old) {  /* destroyed now, or by the last call still running on it */
+        old->retired = 1;
+        old->users++;
+        box_release(old);
+    }
     Py_RETURN_NONE;
 }
 
 static PyObject* p_handle(PyObject* self, PyObject* args) {
     (void)self;
     (void)args;
-    return PyLong_FromVoidPtr(g_ctx);
+    return PyLong_FromVoidPtr(g_box ? g_box->ctx : NULL);
 }
 
-static PyObject* p_encode(PyObject* self, PyObject* args) {
-    (void)self;
-    if (!g_ctx) {
-        PyErr_SetString(PyExc_RuntimeError, NOT_INIT_ENCODE);
-        return NULL;
-    }
+static PyObject* encode_on(hutk_ctx* ctx, PyObject* args) {
     const char* text = NULL;
     if (!PyArg_ParseTuple(args, "s", &text)) return NULL;  /* embedded NUL: ValueError, as in the reference */
     const int64_t len = (int64_t)strlen(text);
-    const int64_t cap = hutk_ids_capacity(g_ctx, len, 1);
+    const int64_t cap = hutk_ids_capacity(ctx, len, 1);
     int32_t* ids = malloc(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1));
     if (!ids) return PyErr_NoMemory();
     int64_t n = 0;
     int rc;
     Py_BEGIN_ALLOW_THREADS
-    rc = hutk_encode(g_ctx, (const uint8_t*)text, len, ids, cap, &n, NULL);
+    rc = hutk_encode(ctx, (const uint8_t*)text, len, ids, cap, &n, NULL);
     Py_END_ALLOW_THREADS
     PyObject* out = NULL;
     if (rc != HUTK_OK && rc != HUTK_E_WORD_TOO_LARGE) raise_code(rc);  /* an over-long word is not reported (lib.c:692-697) */
@@ -154,12 +178,7 @@ static PyObject* p_encode(PyObject* self, PyObject* args) {
     return out;
 }
 
-static PyObject* p_batch_encode(PyObject* self, PyObject* args) {
-    (void)self;
-    if (!g_ctx) {
-        PyErr_SetString(PyExc_RuntimeError, NOT_INIT_ENCODE);
-        return NULL;
-    }
+static PyObject* batch_encode_on(hutk_ctx* ctx, PyObject* args) {
     PyObject* texts = NULL;
     int num_threads = 1;
     if (!PyArg_ParseTuple(args, "O|i", &texts, &num_threads) || !PyList_Check(texts)) {
@@ -193,7 +212,7 @@ static PyObject* p_batch_encode(PyObject* self, PyObject* args) {
         total += len;
         offs[i + 1] = total;
     }
-    const int64_t cap = hutk_ids_capacity(g_ctx, total, n);
+    const int64_t cap = hutk_ids_capacity(ctx, total, n);
     uint8_t* bytes = malloc((size_t)(total + 64));
     int32_t* ids = malloc(sizeof(int32_t) * (size_t)(cap > 0 ? cap : 1));
     int64_t* oo = malloc(sizeof(int64_t) * (size_t)(n + 1));
@@ -204,7 +223,7 @@ static PyObject* p_batch_encode(PyObject* self, PyObject* args) {
     for (Py_ssize_t i = 0; i < n; i++) memcpy(bytes + offs[i], ptrs[i], (size_t)(offs[i + 1] - offs[i]));
     int rc;
     Py_BEGIN_ALLOW_THREADS
-    rc = hutk_encode_batch(g_ctx, bytes, offs, n, ids, cap, oo, NULL);
+    rc = hutk_encode_batch(ctx, bytes, offs, n, ids, cap, oo, NULL);
     Py_END_ALLOW_THREADS
     PyObject* out = NULL;
     if (rc != HUTK_OK && rc != HUTK_E_WORD_TOO_LARGE) {  /* an over-long word ends its document silently (core.c:503) */
@@ -240,19 +259,19 @@ static PyObject* text_of(const uint8_t* p, int64_t n) {  /* PyUnicode_FromString
     return PyUnicode_DecodeUTF8((const char*)p, z ? (Py_ssize_t)(z - p) : (Py_ssize_t)n, NULL);
 }
 
-static PyObject* decode_docs(const int32_t* ids, const int64_t* id_offs, int64_t n_docs) {
+static PyObject* decode_docs(hutk_ctx* ctx, const int32_t* ids, const int64_t* id_offs, int64_t n_docs) {
     int64_t* oo = malloc(sizeof(int64_t) * (size_t)(n_docs + 1));
     if (!oo) return PyErr_NoMemory();
     int rc;
     Py_BEGIN_ALLOW_THREADS
-    rc = hutk_decode_batch(g_ctx, ids, id_offs, n_docs, NULL, 0, oo, NULL);  /* sizes */
+    rc = hutk_decode_batch(ctx, ids, id_offs, n_docs, NULL, 0, oo, NULL);  /* sizes */
     Py_END_ALLOW_THREADS
     if (rc != HUTK_OK) { free(oo); return raise_code(rc); }
     const int64_t total = oo[n_docs];
     uint8_t* bytes = malloc((size_t)(total + 16));
     if (!bytes) { free(oo); return PyErr_NoMemory(); }
     Py_BEGIN_ALLOW_THREADS
-    rc = hutk_decode_batch(g_ctx, ids, id_offs, n_docs, bytes, total, oo, NULL);
+    rc = hutk_decode_batch(ctx, ids, id_offs, n_docs, bytes, total, oo, NULL);
     Py_END_ALLOW_THREADS
     PyObject* out = NULL;
     if (rc != HUTK_OK) {
@@ -270,12 +289,7 @@ static PyObject* decode_docs(const int32_t* ids, const int64_t* id_offs, int64_t
     return out;
 }
 
-static PyObject* p_decode(PyObject* self, PyObject* args) {
-    (void)self;
-    if (!g_ctx) {
-        PyErr_SetString(PyExc_RuntimeError, NOT_INIT_DECODE);
-        return NULL;
-    }
+static PyObject* decode_on(hutk_ctx* ctx, PyObject* args) {
     PyObject* tokens = NULL;
     if (!PyArg_ParseTuple(args, "O", &tokens)) {
         PyErr_SetString(PyExc_TypeError, "Failed to parse arguments. Expected a single list of tokens.");
@@ -289,7 +303,7 @@ static PyObject* p_decode(PyObject* self, PyObject* args) {
     int32_t* ids = tokens_of(tokens, &n);
     if (!ids) return NULL;
     const int64_t offs[2] = {0, n};
-    PyObject* l = decode_docs(ids, offs, 1);
+    PyObject* l = decode_docs(ctx, ids, offs, 1);
     free(ids);
     if (!l) return NULL;
     PyObject* s = PyList_GET_ITEM(l, 0);
@@ -298,12 +312,7 @@ static PyObject* p_decode(PyObject* self, PyObject* args) {
     return s;
 }
 
-static PyObject* p_batch_decode(PyObject* self, PyObject* args) {
-    (void)self;
-    if (!g_ctx) {
-        PyErr_SetString(PyExc_RuntimeError, NOT_INIT_DECODE);
-        return NULL;
-    }
+static PyObject* batch_decode_on(hutk_ctx* ctx, PyObject* args) {
     PyObject* tokens = NULL;
     int num_threads = 1;
     if (!PyArg_ParseTuple(args, "O|i", &tokens, &num_threads) || !PyList_Check(tokens)) {
@@ -340,11 +349,29 @@ static PyObject* p_batch_decode(PyObject* self, PyObject* args) {
             ids[offs[i] + j] = (int32_t)v;
         }
     }
-    PyObject* out = decode_docs(ids, offs, n);
+    PyObject* out = decode_docs(ctx, ids, offs, n);
     free(offs);
     free(ids);
     return out;
 }
+
+/* the method table's entries: take the current context, run on it, let go of it */
+#define HUTK_ON_CONTEXT(NAME, IMPL, NOT_INIT)                       \
+    static PyObject* NAME(PyObject* self, PyObject* args) {         \
+        (void)self;                                                 \
+        ctx_box* box = box_acquire();                               \
+        if (!box) {                                                 \
+            PyErr_SetString(PyExc_RuntimeError, NOT_INIT);          \
+            return NULL;                                            \
+        }                                                           \
+        PyObject* out = IMPL(box->ctx, args);                       \
+        box_release(box);                                           \
+        return out;                                                 \
+    }
+HUTK_ON_CONTEXT(p_encode, encode_on, NOT_INIT_ENCODE)
+HUTK_ON_CONTEXT(p_batch_encode, batch_encode_on, NOT_INIT_ENCODE)
+HUTK_ON_CONTEXT(p_decode, decode_on, NOT_INIT_DECODE)
+HUTK_ON_CONTEXT(p_batch_decode, batch_decode_on, NOT_INIT_DECODE)
 
 static PyMethodDef Methods[] = {
     {"initialize", (PyCFunction)p_initialize, METH_VARARGS | METH_KEYWORDS, "Initialize tokenizer"},

@@ -83,3 +83,39 @@ def random_words(lo, hi, n_docs, words_per_doc=20, seed=0x52574f52, lexicon=2000
     offs = np.zeros(n_docs + 1, dtype=np.int64)
     np.cumsum(wl.sum(axis=1), out=offs[1:])
     return np.ascontiguousarray(data), offs
+
+
+def cjk_paragraphs(n_docs, seed=0x434a4b50, lo=100, hi=400, alphabet=3000):
+    """Texts that the reference's splitter takes as FEW, LONG words: paragraphs of lo..hi CJK characters (uniform over
+    `alphabet` code points from U+4E00, a full stop or a comma now and then -- all of one splitter class, so a whole
+    paragraph is one word of 300..1200 bytes, parser.c:102-138), one to four per document with a line feed between.
+    -> (uint8 array, int64 offsets[n_docs+1]); numpy's PCG64 with a fixed seed, identical on every host."""
+    rng = np.random.default_rng(seed)
+    n_par = rng.integers(1, 5, n_docs)
+    plen = rng.integers(lo, hi + 1, int(n_par.sum()))
+    total_chars = int(plen.sum())
+    cp = 0x4E00 + rng.integers(0, alphabet, total_chars)
+    punct = rng.random(total_chars)
+    cp = np.where(punct < 0.03, 0x3002, np.where(punct < 0.08, 0xFF0C, cp)).astype(np.uint32)
+    b = np.empty((total_chars, 3), dtype=np.uint8)
+    b[:, 0] = 0xE0 | (cp >> 12)
+    b[:, 1] = 0x80 | ((cp >> 6) & 0x3F)
+    b[:, 2] = 0x80 | (cp & 0x3F)
+    # a line feed behind every paragraph but a document's last
+    par_end = np.cumsum(plen)                      # in characters
+    doc_last_par = np.cumsum(n_par) - 1
+    is_last = np.zeros(len(plen), dtype=bool)
+    is_last[doc_last_par] = True
+    par_bytes = plen * 3 + (~is_last)
+    out = np.empty(int(par_bytes.sum()), dtype=np.uint8)
+    pos = np.concatenate(([0], np.cumsum(par_bytes)))
+    flat = b.reshape(-1)
+    cstart = np.concatenate(([0], par_end[:-1]))
+    for k in range(len(plen)):  # (a few thousand paragraphs per 1000 documents: fine)
+        out[pos[k]:pos[k] + 3 * plen[k]] = flat[3 * cstart[k]:3 * par_end[k]]
+        if not is_last[k]:
+            out[pos[k] + 3 * plen[k]] = 0x0A
+    doc_bytes = np.add.reduceat(par_bytes, np.concatenate(([0], np.cumsum(n_par)[:-1])))
+    offs = np.zeros(n_docs + 1, dtype=np.int64)
+    np.cumsum(doc_bytes, out=offs[1:])
+    return out, offs

@@ -71,6 +71,32 @@ def test_vg_corpus_round_trip(vg_files, oracle_mod):
     assert np.array_equal(boff, o) and np.array_equal(out, d)  # decode(encode(text)) == text, byte for byte
 
 
+def test_look_back_that_helps_itself(vg_files, monkeypatch):
+    """k_dec_tiles' look-back does not depend on the order in which workgroups start: a tile that has waited long enough
+    for one in front of it adds that tile's bytes up itself.  HUTK_DEC_HELP_AFTER=0 makes every tile do so at its first
+    unanswered poll -- the same text and offsets (character mode with a prefix too: the stripped first tokens)."""
+    from hutoken_amd import synth
+    monkeypatch.setenv("HUTK_DEC_HELP_AFTER", "0")
+    vp, sp, kw = vg_files
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C3", 60000)
+    ids, oo, st, rc = ctx.encode_packed(d, o)
+    assert rc == 0
+    out, boff, st = ctx.decode_packed(ids, oo)
+    assert (st == 0).all()
+    assert np.array_equal(boff, o) and np.array_equal(out, d)
+    from hutoken_amd import data
+    vp, sp, kw = data.vocab_files("VL")
+    ctx = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C5", 30000)
+    ids, oo, st, rc = ctx.encode_packed(d, o)
+    assert rc == 0 and (ids >= 0).all()
+    out, boff, st = ctx.decode_packed(ids, oo)
+    monkeypatch.delenv("HUTK_DEC_HELP_AFTER")
+    out2, boff2, st2 = ctx.decode_packed(ids, oo)
+    assert np.array_equal(boff, boff2) and np.array_equal(out, out2) and np.array_equal(st, st2)
+
+
 def test_errors(tmp_path, oracle_mod):
     ents, sp = H.random_byte_vocab(7, n_merges=100)
     vp, spath = H.write_vocab(tmp_path, "e", ents, sp)

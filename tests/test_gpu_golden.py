@@ -175,6 +175,30 @@ def test_errors_and_limits(tmp_path, oracle_mod):
     assert ids_g[oo_g[2]:oo_g[3]].tolist() == orc.encode(b"hi")
 
 
+def test_g10_replacements_of_several_units(tmp_path):
+    """Special-character replacements of several units (the reference's pretokenizer emits any string, src/pretokenizer.c:
+    102-168; its own tests pin 'a' -> "Alpha", tests/test_pretokenizer.c:38-41): the words that hold such an item go
+    through the exception kernels, which expand it.  Vectors: the compiled reference (tools/make_golden_g10.py)."""
+    import test_g10_cpu as G
+    with open(os.path.join(H.GOLDEN_DIR, "g10_pretokenizer.json")) as f:
+        g10 = json.load(f)
+    for case in g10["pretokenizer"]:
+        if "ids" not in case:
+            continue
+        vp, sp = G.case_files(tmp_path, case)
+        ctx = ctx_for(vp, sp, case["prefix"] or None, case["is_byte_encoder"])
+        assert ctx.encode_one(case["text"].encode("utf-8"))[0] == case["ids"], case["name"]
+        assert ctx.encode_one(("x " + case["text"] + " y " + case["text"]).encode("utf-8"))[0] == case["ids_in_sentence"], case["name"]
+        ctx.close()
+    for g in g10["files"]:
+        vp, sp, mp, texts = G.file_case(tmp_path, g)
+        ctx = ctx_for(vp, sp, g["prefix"], g["kind"] == "byte", mp)
+        res = encode_texts(ctx, texts)
+        assert res[:len(g["first"])] == g["first"], g["seed"]
+        assert sum(len(x) for x in res) == g["n_ids"] and G.sha_ids(res) == g["sha256"], g["seed"]
+        ctx.close()
+
+
 def test_g5_merges_path(tmp_path):
     """The id-keyed merge path (merges file) against the reference's outputs."""
     from hutoken_amd import data, synth

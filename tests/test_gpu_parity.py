@@ -276,8 +276,9 @@ def test_merges_path_random_vocabularies(tmp_path, oracle_mod):
 
 
 def test_merges_path_char_mode(tmp_path, oracle_mod):
-    """Non-byte mode on the id-keyed path: one-character replacements work; the byte-fallback literals of a
-    Llama-style special file are several units per input byte there and are refused at load time."""
+    """Non-byte mode on the id-keyed path: one-character replacements, and the byte-fallback literals of a Llama-style
+    special file -- several units per input byte there (core.c:460-474 splits "<0x0A>" per character): the words with a
+    tab or a line feed go through the exception kernels, which expand them."""
     ents, _sp = H.random_char_vocab(1, n_merges=400)
     vp, spath = H.write_vocab(tmp_path, "mc1", ents, {32: "▁"})
     mp = H.write_merges(tmp_path, "mc1", H.random_merges_text(ents, 5))
@@ -287,11 +288,14 @@ def test_merges_path_char_mode(tmp_path, oracle_mod):
     docs = [H.random_text(rng, max_words=30).replace("\t", " ").replace("\n", " ").replace("\r", " ").encode("utf-8")
             for _ in range(3000)]
     _compare(ctx, orc, docs + [b"", b" ", b"a", b" a"], "merges-char")
-    from hutoken_amd import _capi
     ents2, sp2 = H.random_char_vocab(2, n_merges=100)
     vp2, spath2 = H.write_vocab(tmp_path, "mc2", ents2, sp2)
-    with pytest.raises(Exception, match="one character"):
-        _capi.Context(vp2, spath2, "▁", False, merges_path=mp)
+    mp2 = H.write_merges(tmp_path, "mc2", H.random_merges_text(ents2, 6, noise=False))
+    ctx2 = _ctx(vp2, spath2, "▁", False, mp2)
+    orc2 = oracle_mod.Oracle(vp2, spath2, "▁", False, mp2)
+    rng = random.Random(502)
+    docs2 = [H.random_text(rng, max_words=30).encode("utf-8") for _ in range(2000)]  # tabs and line feeds included
+    _compare(ctx2, orc2, docs2 + [b"\n", b"a\tb", b"\r\n\r\n", b" \n"], "merges-char-literals")
 
 
 def test_merges_path_vg_on_corpora(vg_files, oracle_mod):
@@ -325,6 +329,41 @@ def test_python_surface(vg_files, oracle_mod):
     with pytest.raises(RuntimeError, match="embedded null character"):
         hutoken.encode("a\0b")
     assert hutoken.batch_encode(["ab\0cd"]) == [orc.encode("ab")]
+
+
+def test_initialize_while_another_thread_encodes(vg_files, oracle_mod):
+    """The shim releases the GIL around the C ABI, so initialize() on one thread can replace the module's context while
+    batch_encode() runs on another: the old context lives until the last call on it has returned (no freed streams or
+    device buffers under running kernels), and every call returns the ids of the vocabulary it started with."""
+    import threading
+    import hutoken_amd as hutoken
+    from hutoken_amd import synth
+    vp, sp, kw = vg_files
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    d, o = synth.corpus("C3", 3000, first_doc=123_000)
+    docs = synth.docs_as_str(d, o)
+    want = orc.batch_encode(docs, 8)
+    hutoken.initialize(vp, sp, **kw)
+    stop, bad = threading.Event(), []
+
+    def encoder():
+        while not stop.is_set():
+            got = hutoken.batch_encode(docs, 4)
+            if got != want:
+                bad.append("ids differ")
+            if hutoken.encode(docs[5]) != want[5]:
+                bad.append("encode differs")
+
+    ts = [threading.Thread(target=encoder) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for _ in range(6):
+        hutoken.initialize(vp, sp, **kw)
+    stop.set()
+    for t in ts:
+        t.join()
+    assert not bad
+    assert hutoken.batch_encode(docs[:10], 1) == want[:10]
 
 
 def test_python_surface_with_several_devices(vg_files, oracle_mod, monkeypatch):

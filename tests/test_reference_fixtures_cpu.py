@@ -15,7 +15,6 @@ import make_golden_g8 as G8  # noqa: E402  (only its seeded file builders: the r
 
 # file shapes the device tables refuse at load although the reference accepts them
 REFUSED_BY_DESIGN = {
-    "special_value_of_one_chunk": ValueError,         # a replacement of twenty units per input byte
     "special_last_line_without_newline": ValueError,  # the dropped last byte leaves half a character as byte 173's replacement
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel GPU time of one device-resident batch of a named workload (run under rocprofv3 --kernel-trace --stats):
-  kernel_times.py C3 200000 | kernel_times.py words 70 120 [docs]"""
+  kernel_times.py C3 200000 | kernel_times.py words 70 120 [docs] | kernel_times.py cjk [docs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,8 @@ vp, sp, kw = data.vocab_files("VG")
 ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
 if sys.argv[1] == "words":
     d, o = synth.random_words(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 100000, 8)
+elif sys.argv[1] == "cjk":
+    d, o = synth.cjk_paragraphs(int(sys.argv[2]) if len(sys.argv) > 2 else 50000)
 else:
     d, o = synth.corpus(sys.argv[1], int(sys.argv[2]))
 n = len(o) - 1

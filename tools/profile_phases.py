@@ -13,6 +13,8 @@ ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
 if name.startswith("words:"):  # words:LO:HI -- random words of LO..HI letters (every word through the merge loop / exception kernels)
     lo, hi = (int(x) for x in name.split(":")[1:3])
     d, o = synth.random_words(lo, hi, n_docs, 8)
+elif name == "cjk":  # paragraphs of CJK characters: under the reference's splitter a few words of ~1 KB per document
+    d, o = synth.cjk_paragraphs(n_docs)
 else:
     d, o = synth.corpus(name, n_docs)
 dev = torch.device("cuda", 0)
