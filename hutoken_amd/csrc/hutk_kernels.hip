@@ -99,6 +99,20 @@ __device__ __forceinline__ int32_t sym_to_id(const DevTables& T, uint32_t s) {
     return s < T.n_sym ? T.sym_id[s] : -1;
 }
 
+// k_cut's notes from a tile (rare, out of line so that the hot path does not carry them): no word start of the
+// reference's own among the tile's positions -> its bit in noreal_bits; starts, but none in the halo -> this may be the
+// tile in front of a run, and its last start is where k_cut would cut: 1 + position into *cutpos (LDS; the ids in front
+// of it are counted in the epilogue).
+__device__ __noinline__ void cut_note_cold(Workspace W, uint32_t tile, unsigned long long mine, uint32_t last16, uint32_t* cutpos) {
+    if ((threadIdx.x & 63) != 0) return;
+    if (mine == 0) {
+        atomicOr(&W.noreal_bits[tile >> 5], 1u << (tile & 31));
+        atomicAdd(&W.counters[6], 1u);
+    } else {  // last16: the starts (without seams) of the tile's last lane that has one
+        *cutpos = 1u + (uint32_t)(16 * (63 - __builtin_clzll(mine)) + 31 - __builtin_clz(last16 & 0xFFFFu));
+    }
+}
+
 // Out of line on purpose: the per-position form indexes its window dynamically (scratch), and inlined that
 // would put a scratch store of the window on the hot path of every tile.
 struct Win8 { uint32_t d[8]; };  // by value: the window travels in registers
@@ -329,9 +343,12 @@ struct TileLds {
     uint32_t arena_live[ARENA_WORDS];  // their surviving units
     uint16_t arena_ws[ARENA_WORDS], arena_n[ARENA_WORDS];
     uint32_t arena_used, extra;  // arena slots taken; extra ids granted (<= RUN_EXTRA)
+    uint32_t cutpos;             // k_cut: 1 + position of the tile's last word start of the reference's own, when none follows in the halo; else 0
 };
 
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES>
+// MULTI: the vocabulary has special-character replacements of several units (rare): a word that holds such an item is an
+// exception word.  A build of its own, because even as a uniform branch the test costs the ordinary kernel 2.5 %.
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, bool MULTI = false>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
@@ -431,7 +448,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
     const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
-    uint32_t real_own = 0, halo_real = 1;  // ... without the seams; the same of the halo's 64 positions, one bit per lane
     for (int i = threadIdx.x; i < (dfa::TABLE_BYTES + 256) / 16; i += 64 * WAVES) {
         const uint4 v = T.split_dfa[i];
         reinterpret_cast<uint4*>(&s_m.c)[i] = v;  // table, then byte classes, as uploaded
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         }
         if (lane < WINDOW / 32 + 3) docm[lane] = 0;
         if (lane < NPOS / 32 + 2) { mergem[lane] = 0; excm[lane] = 0; livem[lane] = 0; }
-        if (lane == 0) { s_arena_used = 0; s_extra = 0; }
+        if (lane == 0) { s_arena_used = 0; s_extra = 0; me.cutpos = 0; }
         if (lane < ARENA_WORDS) { arena_ws[lane] = 0xFFFFu; arena_live[lane] = 0; }
         if (lane < 8) wmask16[64 + lane] = 0xFFFFu;
         wave_sync();
@@ -484,7 +500,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             w.a = src[0]; w.b = src[1]; w.c = src[2]; w.d = src[3];
         }
         const uint32_t dbits = (uint32_t)bits64(docm, kb - 8);
-        uint32_t flags, flags_real;  // word starts of my 16 positions; the same without the seams
+        uint32_t flags;  // word starts of my 16 positions
+        unsigned long long with_start;
+        uint32_t last_real16;
         {
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
@@ -504,7 +522,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
                 flags = classify16_exact_cold(w8, dbits);
             }
-            flags_real = flags;
+            // The reference ends a document at a word of more than 262144 bytes (core.c:402-407).  With seams such a word can
+            // be a run of short ones here, so k_cut looks for what every such word leaves behind: at least 272 tiles in
+            // a row without a start of the reference's own (taken here, before the seams come in).  Normal text never
+            // sets a bit.
+            // (k_cut, below: the lanes with a word start of the reference's own, and the starts of the last such lane of the tile)
+            with_start = __ballot(flags != 0);
+            last_real16 = (uint32_t)__builtin_amdgcn_readlane((int)flags, 63 - __builtin_clzll((with_start & 0x0FFFFFFFFFFFFFFFull) | 1ull));
             if (T.seam_on && !A.word_bits) {
                 // Seams (hutk_internal.h, Tables::seam_hi): where no merge can join the input byte x to the lead byte y of the
                 // three- or four-byte character behind it, the word's encoding is the concatenation of the encodings of
@@ -570,25 +594,28 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         //   excm   starts of exception words
         const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
         own = flags;                             // starts that are words of this tile
-        real_own = flags_real;
         {
             const int lo = 16 * lane;
             if (lo >= limit) own = 0;
             else if (lo + 16 > limit) own &= (1u << (limit - lo)) - 1u;
-            real_own &= own;
         }
-        // The reference ends a document at a word of more than 262144 bytes (core.c:402-407).  With seams such a word can
-        // be a run of short ones here, so k_cut looks for what every such word leaves behind: at least 272 tiles in a
-        // row without a start of the reference's own.  Normal text never sets a bit.
-        halo_real = (uint32_t)(__ballot(flags_real != 0) >> 60);
-        if (!A.word_bits && !__any(real_own != 0) && lane == 0) {
-            atomicOr(&W.noreal_bits[tile >> 5], 1u << (tile & 31));
-            atomicAdd(&W.counters[6], 1u);
+        if (!A.word_bits && HUTK_LAB_NO_CUTFLAGS != 1) {
+            // The reference ends a document at a word of more than 262144 bytes (core.c:402-407).  With seams such a word can
+            // be a run of short ones here, so k_cut looks for what every such word leaves behind: at least 272 tiles in
+            // a row without a start of the reference's own (with_start: taken before the seams came in).  The lanes
+            // whose positions are data of this tile: a last lane that is only partly data counts whole, which can only leave
+            // the batch's last tile unmarked, and k_cut counts whole tiles.  Both cases are rare and live out of line.
+            const unsigned long long mine = with_start & ((1ull << ((limit + 15) >> 4)) - 1ull);
+            if (mine == 0 || (with_start >> 60) == 0)
+                cut_note_cold(W, (uint32_t)tile, mine, last_real16, &me.cutpos);
         }
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
         uint32_t nW;
         const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
         uint32_t rest = own, widx = wbase;  // my word starts not yet handed out, and the index of the first of them
+#if HUTK_LAB_ALIGN
+        asm volatile(".p2align " HUTK_STR(HUTK_LAB_ALIGN));
+#endif
         for (uint32_t r0 = 0; r0 < nW; r0 += 64) {
             while (rest && widx - r0 < 64u) {  // (each start is visited once, in the round it belongs to)
                 stage[widx - r0] = (uint16_t)(16 * lane + __builtin_ctz(rest));
@@ -613,7 +640,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const bool gap = A.gap_bits && ((A.gap_bits[(t0 + ws) >> 5] >> ((t0 + ws) & 31)) & 1u);
                 const bool pfx = !gap && T.has_prefix && docfirst && b0 != ' ';
                 bool exc = !gap && (!known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst));
-                if (T.has_multi && !gap && !exc) {
+                if (MULTI && !gap && !exc) {
                     // an item whose replacement has several units, or none (pretokenizer.c:102-168 emits any string): the
                     // word's units are not one per item; the exception kernels expand it (uniform branch, rare vocabularies)
                     bool m = false;
@@ -925,79 +952,68 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #endif
                 // A lookup that must go on in the pair's SECOND bucket (a filter bit of the first one says so; under 1 % of
                 // the lookups) is not followed up inside the trip: with 64 lanes and two lookups each, nearly every trip
-                // had some lane in that case, and every lane paid its extra round trip(s).  The lane keeps its trip's state
-                // in two registers instead and REPEATS both lookups in the next trip, from the buckets they need, beside
-                // the other lanes' ordinary ones.  rsA: p | p0 << 5 | has right << 10 | has left << 11 |
-                // {right, left} lookup from its second bucket << 12 | merged << 16 (never 0 in a repeat); rsB: sr | sl << 16.
-                uint32_t rsA = 0, rsB = 0;
+                // had some lane in that case, and every lane paid its extra round trip(s).  The lane remembers which of its
+                // two lookups it was (`again`) and REPEATS both in the next trip, from the buckets they need, beside the
+                // other lanes' ordinary ones: its merge is applied already, so the same code finds the same neighbours.
+                uint32_t again = 0;  // bit 0 / 1: the right / left lookup of the merge at p goes to its second bucket this trip
+                int p = 0;
+#if HUTK_LAB_ALIGN
+                asm volatile(".p2align " HUTK_STR(HUTK_LAB_ALIGN));
+#endif
                 for (;;) {
 #if HUTK_MERGE_STAMPS
                     const long long tt0 = clock64();
                     long long tt1 = tt0, tt2 = tt0;
 #endif
-                    have = have && (best != NOKEY || rsA != 0);
+                    have = have && (best != NOKEY || again != 0);
                     if (!__any(have)) break;
                     if (have) {
-                        int p, p0;
-                        uint32_t merged, sr, sl, b1, b2, t1, t2, second = 0;
-                        bool right, left;
-                        if (rsA == 0) {
+                        uint32_t merged;
+                        if (again == 0) {
                             p = (int)(best & 31u);
                             merged = best >> 5;
                             const uint32_t above = live & ~((2u << p) - 1u);  // not empty: bit p of cand was set
                             const int q = __builtin_ctz(above);               // the unit the merge consumes
                             Sw[p] = (SymT)merged;
                             live &= ~(1u << q);
-                            const uint32_t rmask = above & (above - 1u);    // live units after q
-                            const uint32_t lmask = live & ((1u << p) - 1u);  // live units before p: none iff p == 0
-                            right = rmask != 0;
-                            left = lmask != 0;
-                            const int q2 = __builtin_ctz(rmask | 0x80000000u);
-                            p0 = 31 - __builtin_clz(lmask | 1u);            // == p when there is none
-                            sr = Sw[q2];
-                            sl = Sw[p0];                                      // (read and looked up even when absent)
-                            t1 = pair_mix(merged, sr);
-                            t2 = pair_mix(sl, merged);
-                            b1 = pair_bucket1(t1, T.pair_shift);
-                            b2 = pair_bucket1(t2, T.pair_shift);
-                            cand &= ~((1u << q) | (1u << p) | (1u << p0));
+                            cand &= ~((1u << q) | (1u << p));
                         } else {
-                            p = (int)(rsA & 31u);
-                            p0 = (int)((rsA >> 5) & 31u);
-                            right = (rsA >> 10) & 1u;
-                            left = (rsA >> 11) & 1u;
-                            second = (rsA >> 12) & 3u;
-                            merged = rsA >> 16;
-                            sr = rsB & 0xFFFFu;
-                            sl = rsB >> 16;
-                            t1 = pair_mix(merged, sr);
-                            t2 = pair_mix(sl, merged);
-                            b1 = (second & 1u) ? pair_bucket2(t1, T.pair_shift) : pair_bucket1(t1, T.pair_shift);
-                            b2 = (second & 2u) ? pair_bucket2(t2, T.pair_shift) : pair_bucket1(t2, T.pair_shift);
+                            merged = Sw[p];  // the merge is applied: the same code finds the same neighbours
+                        }
+                        const uint32_t rmask = live & ~((2u << p) - 1u);  // live units after p (the consumed one is gone)
+                        const uint32_t lmask = live & ((1u << p) - 1u);   // live units before p: none iff p == 0
+                        const int q2 = __builtin_ctz(rmask | 0x80000000u);
+                        const int p0 = 31 - __builtin_clz(lmask | 1u);    // == p when there is none
+                        const uint32_t sr = Sw[q2], sl = Sw[p0];          // (read and looked up even when absent)
+                        const uint32_t t1 = pair_mix(merged, sr), t2 = pair_mix(sl, merged);
+                        uint32_t b1 = pair_bucket1(t1, T.pair_shift), b2 = pair_bucket1(t2, T.pair_shift);
+                        if (again != 0) {  // (rare, and only the repeating lanes)
+                            if (again & 1u) b1 = pair_bucket2(t1, T.pair_shift);
+                            if (again & 2u) b2 = pair_bucket2(t2, T.pair_shift);
                         }
                         const uint4 e1 = T.pair_buckets[b1], e2 = T.pair_buckets[b2];
 #if HUTK_MERGE_STAMPS
                         tt1 = clock64();
 #endif
-                        if (rsA == 0) best = scan_key(cand);  // (a repeating lane's rescan is done)
+                        if (again == 0) {  // (a repeating lane's rescan is done)
+                            cand &= ~(1u << p0);
+                            best = scan_key(cand);
+                        }
 #if HUTK_MERGE_STAMPS
                         tt2 = clock64();
 #endif
                         const uint32_t y1 = pair_match(e1, merged | ((sr & 0xFFFu) << 20), sr >> 12);
                         const uint32_t y2 = pair_match(e2, sl | ((merged & 0xFFFu) << 20), merged >> 12);
                         const uint32_t f1 = (e1.y >> 28) | ((e1.w >> 28) << 4), f2 = (e2.y >> 28) | ((e2.w >> 28) << 4);
-                        const bool need1 = right && y1 == 0xFFFFFFFFu && !(second & 1u) && ((f1 >> (t1 & 7u)) & 1u);
-                        const bool need2 = left && y2 == 0xFFFFFFFFu && !(second & 2u) && ((f2 >> (t2 & 7u)) & 1u);
+                        const bool need1 = rmask != 0 && y1 == 0xFFFFFFFFu && !(again & 1u) && ((f1 >> (t1 & 7u)) & 1u);
+                        const bool need2 = lmask != 0 && y2 == 0xFFFFFFFFu && !(again & 2u) && ((f2 >> (t2 & 7u)) & 1u);
                         if (need1 || need2) {
-                            second |= (need1 ? 1u : 0u) | (need2 ? 2u : 0u);
-                            rsA = (uint32_t)p | ((uint32_t)p0 << 5) | ((right ? 1u : 0u) << 10) | ((left ? 1u : 0u) << 11) |
-                                  (second << 12) | (merged << 16);
-                            rsB = sr | (sl << 16);
+                            again |= (need1 ? 1u : 0u) | (need2 ? 2u : 0u);
                         } else {
-                            rsA = 0;
+                            again = 0;
                             uint32_t mr = (y1 >> 8) & 0xFFFFFu, ml = (y2 >> 8) & 0xFFFFFu;
-                            mr = (right && mr != PAIR_ABSENT) ? mr : SYM_NONE;
-                            ml = (left && ml != PAIR_ABSENT) ? ml : SYM_NONE;
+                            mr = (rmask != 0 && mr != PAIR_ABSENT) ? mr : SYM_NONE;
+                            ml = (lmask != 0 && ml != PAIR_ABSENT) ? ml : SYM_NONE;
                             Mw[p0] = (SymT)ml;  // first: without a left neighbour p0 == p
                             Mw[p] = (SymT)mr;
                             const bool hr = mr != SYM_NONE, hl = ml != SYM_NONE;
@@ -1180,9 +1196,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     auto extra_ids = [&](int lr, uint32_t starts) -> uint32_t {
         uint32_t x = 0;
         if (PREFIXED && T.has_prefix)
-            for (uint32_t m = starts; m; m &= m - 1) {
+            // (only the words that begin a document: one 16-bit slice of the document-start bitmap instead of a test per word)
+            for (uint32_t m = starts & (uint32_t)bits64(docm, 16 * lr + LOOKBACK) & 0xFFFFu; m; m &= m - 1) {
                 const int ws = 16 * lr + __builtin_ctz(m);
-                if (!bit_at(docm, ws + LOOKBACK) || bit_at(excm, ws)) continue;
+                if (bit_at(excm, ws)) continue;
                 const int a = arena_at(ws);
                 x += a >= 0 ? (uint32_t)__popc(arena_live[a]) : alone_ids(ws);
             }
@@ -1264,17 +1281,15 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 
     // ... and before the tile's last start of the reference's own, when none follows in the halo: that is where k_cut
     // cuts a document if the word turns out to be over-long (rare: a word of 64 bytes and more)
-    if (!A.word_bits && halo_real == 0) {
-        const unsigned long long rb = __ballot(real_own != 0);
-        if (rb) {
-            const int lr = 63 - __builtin_clzll(rb);
-            const uint32_t r16 = (uint32_t)__shfl((int)real_own, lr, 64);
-            const int pos = 16 * lr + 31 - __builtin_clz(r16);
+    if (const uint32_t cp = me.cutpos; cp != 0) {  // (rare)
+        if (lane == 0) {
+            const int pos = (int)cp - 1;
+            const int lr = pos >> 4;
             const uint32_t below = (1u << (pos & 15)) - 1u;
             uint32_t before = lanepref[lr];
             before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(livem)[lr] & below);
             before += extra_ids(lr, wmask16[lr] & below);
-            if (lane == 0) W.tile_lastreal[tile] = (uint32_t)pos | (before << 16);
+            W.tile_lastreal[tile] = (uint32_t)pos | (before << 16);
         }
     }
     // ---- 8. ids emitted before each document that starts in this tile ----------
@@ -2596,8 +2611,11 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
     // transition table in LDS (one tile per workgroup outside byte-encoder mode was 17 % slower once the table
     // was there: fewer resident wavefronts)
 #define HUTK_LAUNCH(ST, BM, RS, WV)                                                                     \
-    hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV>), dim3((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), dim3(64 * WV), 0, s, \
-                       t, a, w)
+    do {                                                                                                \
+        const dim3 g_((unsigned)(((a.n_tiles + WV - 1) / WV + 7) / 8 * 8)), b_(64 * WV);                \
+        if (t.has_multi) hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV, true>), g_, b_, 0, s, t, a, w);   \
+        else hipLaunchKernelGGL((k_tiles<ST, BM, RS, WV, false>), g_, b_, 0, s, t, a, w);              \
+    } while (0)
     const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
     switch (variant) {
         case 7: HUTK_LAUNCH(uint16_t, true, true, TILE_WAVES); break;

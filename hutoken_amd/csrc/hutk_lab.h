@@ -22,6 +22,14 @@
 #ifndef HUTK_MERGE_STAMPS
 #define HUTK_MERGE_STAMPS 0
 #endif
+#ifndef HUTK_LAB_NO_CUTFLAGS
+#define HUTK_LAB_NO_CUTFLAGS 0  // 1: k_tiles does not look for tiles without a word start (k_cut then never cuts: WRONG for over-long words)
+#endif
+#ifndef HUTK_LAB_ALIGN
+#define HUTK_LAB_ALIGN 0  // n: the round loop and the trip loop of k_tiles start on a 2^n-byte boundary (is a few per cent of difference between two builds code placement?)
+#endif
+#define HUTK_STR2(x) #x
+#define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD
 #define HUTK_LAB_LDS_PAD 0  // bytes of unused LDS per workgroup of k_tiles: fewer resident workgroups (is the kernel bound by latency or by issue?)
 #endif

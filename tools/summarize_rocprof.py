@@ -100,21 +100,33 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
           "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
     json.dump(tj, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     lines += [f"HBM-side traffic per k_tiles launch (corrected): {traffic / 1e9:.3f} GB", ""]
-# The limit that binds k_tiles: VALU issue.  A wave64 VALU instruction occupies one of the 1024 SIMDs for 4 cycles;
-# GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+# VALU issue.  What a wave64 VALU instruction costs a SIMD is measured (tools/valu_issue_bench.hip): 2 cycles for a few
+# simple opcodes when two wavefronts pair up, 4 otherwise; profiles/r03_issue_model.json prices the kernel's opcode mix
+# with it ("paired" = every simple opcode finds a partner, "unpaired" = none does).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
 if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
     cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0
     ij = {"tag": tag, "kernel": "k_tiles", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
           "salu_insts_per_launch": pmc.get("SQ_INSTS_SALU"), "lds_insts_per_launch": pmc.get("SQ_INSTS_LDS"),
           "busy_cycles_per_launch": cycles, "kernel_ms_profiled": pmc_ms.get("GRBM_GUI_ACTIVE"),
           "valu_issue_frac": pmc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
+          "wait_any_frac": (pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES") else None,
           "lds_bank_conflict_frac": (pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"])
           if "SQ_LDS_BANK_CONFLICT" in pmc and pmc.get("SQ_LDS_IDX_ACTIVE") else None,
           "ta_busy_frac": (pmc["TA_BUSY_avr"] / cycles) if "TA_BUSY_avr" in pmc else None,
           "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
     json.dump(ij, open(os.path.join(dst, f"{tag}_issue.json"), "w"), indent=1)
-    lines += [f"VALU issue: {ij['valu_insts_per_launch']:.4g} wave-instructions x 4 cycles / (1024 SIMDs x {cycles:.4g} cycles) = "
-              f"{ij['valu_issue_frac']:.3f} of the launch's SIMD cycles", ""]
+    try:
+        model = json.load(open(os.path.join(dst, "r03_issue_model.json")))
+        c_lo, c_hi = model["cycles_per_valu_inst_paired"], model["cycles_per_valu_inst_unpaired"]
+    except Exception:
+        c_lo, c_hi = 2.0, 4.0
+    ij["valu_issue_frac_range"] = [pmc["SQ_INSTS_VALU"] * c_lo / (1024.0 * cycles), pmc["SQ_INSTS_VALU"] * c_hi / (1024.0 * cycles)]
+    json.dump(ij, open(os.path.join(dst, f"{tag}_issue.json"), "w"), indent=1)
+    lines += [f"VALU issue: {ij['valu_insts_per_launch']:.4g} wave-instructions x {c_lo:.2f} .. {c_hi:.2f} cycles (measured cost of the "
+              f"kernel's opcode mix, every simple opcode paired .. none) / (1024 SIMDs x {cycles:.4g} cycles) = "
+              f"{ij['valu_issue_frac_range'][0]:.3f} .. {ij['valu_issue_frac_range'][1]:.3f} of the launch's SIMD cycles", ""]
+    if ij["wait_any_frac"] is not None:
+        lines += [f"Wavefronts parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES): {ij['wait_any_frac']:.3f}", ""]
     if ij["lds_bank_conflict_frac"] is not None:
         lines += [f"LDS bank conflicts: {ij['lds_bank_conflict_frac']:.3f} of the LDS-active cycles", ""]
     if ij["ta_busy_frac"] is not None:
