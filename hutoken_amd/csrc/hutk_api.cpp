@@ -86,7 +86,7 @@ struct hutk_ctx {
     bool profile = false;
     // regex pre-token path: the pattern of initialize() (empty: the hand-written splitter) and the bitmaps of a batch
     std::string pattern;
-    DevBuf<uint32_t> w_wbits, w_gbits;
+    DevBuf<uint32_t> w_wbits, w_gbits, w_fbits, w_abits;
     DevTables dt{};
 
     // workspace
@@ -376,7 +376,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release(); c->d_item_units.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release();
+        c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release(); c->w_fbits.release(); c->w_abits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
@@ -644,16 +644,64 @@ int hutk_debug_profile_raw(hutk_ctx* c, int64_t n_tiles, long long* out) {
 static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
                               int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap, int64_t* d_out_offsets,
                               int32_t* d_status, int32_t* d_err, void* hip_stream, const uint32_t* d_word_bits,
-                              const uint32_t* d_gap_bits);
+                              const uint32_t* d_gap_bits, const uint32_t* d_first_bits = nullptr,
+                              const uint32_t* d_alone_bits = nullptr);
+
+static int regex_bitmaps(const std::string& pattern, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
+                         std::vector<uint32_t>& wbits, std::vector<uint32_t>& gbits, std::vector<uint8_t>& too_large,
+                         std::vector<uint32_t>* fbits, std::vector<uint32_t>* abits);
 
 int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets,
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap,
                              int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err,
                              void* hip_stream) {
-    if (c && !c->pattern.empty())
-        return set_err(HUTK_E_UNSUPPORTED,
-                       "a context with a regex pattern splits on the host (libc regexec): give it host buffers "
-                       "(hutk_encode_batch)");
+    if (c && !c->host_only && !c->pattern.empty()) {
+        // The regex pre-token path splits with libc's regexec (core.c:350-378), which runs on the host: the bytes and offsets
+        // come down once, the bitmaps of the matches go up, and the encode itself stays on the device buffers.  This form
+        // of the call therefore SYNCHRONISES with the stream (the only one that does).
+        if (n_docs < 0 || n_bytes < 0 || !d_offsets || (n_bytes > 0 && !d_bytes)) return set_err(HUTK_E_ARG, "bad argument");
+        std::lock_guard<std::recursive_mutex> lock(c->mu);
+        HIP_TRY(hipSetDevice(c->device));
+        hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+        std::vector<uint8_t> hb((size_t)n_bytes + 1);
+        std::vector<int64_t> ho((size_t)n_docs + 1);
+        if (n_bytes) HIP_TRY(hipMemcpyAsync(hb.data(), d_bytes, (size_t)n_bytes, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ho.data(), d_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (ho[0] != 0 || ho[(size_t)n_docs] != n_bytes) return set_err(HUTK_E_ARG, "n_bytes must equal offsets[n_docs]");
+        for (int64_t i = 0; i < n_docs; i++)
+            if (ho[(size_t)i + 1] < ho[(size_t)i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
+        if (memchr(hb.data(), 0, (size_t)n_bytes)) return set_err(HUTK_E_NUL_BYTE, "a document contains a 0x00 byte");
+        std::vector<uint32_t> wbits, gbits, fbits, abits;
+        std::vector<uint8_t> too_large;
+        const bool pfx = c->tab.has_prefix;
+        int rc = regex_bitmaps(c->pattern, hb.data(), ho.data(), n_docs, wbits, gbits, too_large, pfx ? &fbits : nullptr,
+                               pfx ? &abits : nullptr);
+        if (rc) return set_err(rc, "Regex could not be compiled.");
+        if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(s, c->ev_busy, 0));  // (the bitmaps are the context's: the previous call may still read them)
+        HIP_TRY(c->w_wbits.reserve(wbits.size()));
+        HIP_TRY(c->w_gbits.reserve(gbits.size()));
+        HIP_TRY(hipMemcpyAsync(c->w_wbits.p, wbits.data(), wbits.size() * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(c->w_gbits.p, gbits.data(), gbits.size() * 4, hipMemcpyHostToDevice, s));
+        if (pfx) {
+            HIP_TRY(c->w_fbits.reserve(fbits.size()));
+            HIP_TRY(c->w_abits.reserve(abits.size()));
+            HIP_TRY(hipMemcpyAsync(c->w_fbits.p, fbits.data(), fbits.size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->w_abits.p, abits.data(), abits.size() * 4, hipMemcpyHostToDevice, s));
+        }
+        rc = encode_device_impl(c, d_bytes, d_offsets, n_docs, n_bytes, d_ids_out, ids_cap, d_out_offsets, d_status, d_err,
+                                hip_stream, c->w_wbits.p, c->w_gbits.p, pfx ? c->w_fbits.p : nullptr, pfx ? c->w_abits.p : nullptr);
+        if (rc) return rc;
+        if (d_status) {  // a match over the reference's limit ends its document (found by the host: core.c:402-407)
+            for (int64_t d = 0; d < n_docs; d++)
+                if (too_large[(size_t)d]) {
+                    const int32_t st = HUTK_DOC_WORD_TOO_LARGE;
+                    HIP_TRY(hipMemcpyAsync(d_status + d, &st, 4, hipMemcpyHostToDevice, s));
+                }
+        }
+        HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above are the copies' sources)
+        return HUTK_OK;
+    }
     return encode_device_impl(c, d_bytes, d_offsets, n_docs, n_bytes, d_ids_out, ids_cap, d_out_offsets, d_status, d_err,
                               hip_stream, nullptr, nullptr);
 }
@@ -661,7 +709,7 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
 static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
                               int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap, int64_t* d_out_offsets,
                               int32_t* d_status, int32_t* d_err, void* hip_stream, const uint32_t* d_word_bits,
-                              const uint32_t* d_gap_bits) {
+                              const uint32_t* d_gap_bits, const uint32_t* d_first_bits, const uint32_t* d_alone_bits) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
     if (n_docs < 0 || n_bytes < 0 || !d_offsets || !d_out_offsets || (n_bytes > 0 && (!d_bytes || !d_ids_out)))
@@ -695,6 +743,8 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     A.err = d_err ? d_err : c->w_err.p;
     A.word_bits = d_word_bits;
     A.gap_bits = d_gap_bits;
+    A.first_bits = d_first_bits;
+    A.alone_bits = d_alone_bits;
 
     c->ev_valid = false;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[0], s));
@@ -763,12 +813,16 @@ static int64_t pipe_chunk_bytes(int64_t n_bytes) {  // an eighth of the batch, 1
 // calls -- and yields two bitmaps over the batch's bytes: where a word or a dropped stretch begins, and which of those
 // are dropped stretches.  Pretokenizer and merge loop then run on the GPU as for the hand-written splitter.
 // A word over the reference's limit (core.c:402-407) ends its document: the rest becomes a dropped stretch.
+// fbits / abits (a context with a prefix; else null): the first match of every document, and those of them whose document
+// begins with a space (core.c:364-366: the prefix goes with the first match, in front of it or as a word of its own)
 static int regex_bitmaps(const std::string& pattern, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
-                         std::vector<uint32_t>& wbits, std::vector<uint32_t>& gbits, std::vector<uint8_t>& too_large) {
+                         std::vector<uint32_t>& wbits, std::vector<uint32_t>& gbits, std::vector<uint8_t>& too_large,
+                         std::vector<uint32_t>* fbits, std::vector<uint32_t>* abits) {
     const int64_t n_bytes = offsets[n_docs];
     const size_t n_words = (size_t)(n_bytes / 32 + 40);  // (a tile reads the bits of its whole 1024-position window)
     wbits.assign(n_words, 0u);
     gbits.assign(n_words, 0u);
+    if (fbits) { fbits->assign(n_words, 0u); abits->assign(n_words, 0u); }
     too_large.assign((size_t)(n_docs ? n_docs : 1), 0);
     auto set_bit = [](std::vector<uint32_t>& v, int64_t p) {
         __atomic_fetch_or(&v[(size_t)(p >> 5)], 1u << (p & 31), __ATOMIC_RELAXED);
@@ -788,6 +842,7 @@ static int regex_bitmaps(const std::string& pattern, const uint8_t* bytes, const
             if (len <= 0) continue;
             z.assign(reinterpret_cast<const char*>(bytes + base), (size_t)len);  // NUL-terminated copy
             int64_t pos = 0, covered = 0;
+            bool first = true;
             auto gap_to = [&](int64_t upto) {  // [covered, upto) belongs to no word
                 if (upto > covered) { set_bit(wbits, base + covered); set_bit(gbits, base + covered); }
             };
@@ -803,6 +858,11 @@ static int regex_bitmaps(const std::string& pattern, const uint8_t* bytes, const
                 if (wl * 64 > 16ll * 1024 * 1024) { too_large[(size_t)d] = 1; break; }
                 gap_to(ws);
                 set_bit(wbits, base + ws);
+                if (first && fbits) {
+                    set_bit(*fbits, base + ws);
+                    if (z[0] == ' ') set_bit(*abits, base + ws);
+                }
+                first = false;
                 covered = pos = ws + wl;
             }
             gap_to(len);
@@ -836,8 +896,6 @@ int hutk_ctx_set_pattern(hutk_ctx* c, const char* pattern) {
         assign("");
         return HUTK_OK;
     }
-    if (c->tab.has_prefix)
-        return set_err(HUTK_E_UNSUPPORTED, "a regex pattern together with a prefix is not supported");
     regex_t re;
     if (!*pattern || regcomp(&re, pattern, REG_EXTENDED) != 0)
         return set_err(HUTK_E_VALUE, "Regex could not be compiled.");  // core.c:352-358
@@ -1192,7 +1250,8 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
 
 static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                              int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
-                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits);
+                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits,
+                             const std::vector<uint32_t>* fbits = nullptr, const std::vector<uint32_t>* abits = nullptr);
 
 static int encode_batch_simple(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                                int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status) {
@@ -1208,11 +1267,13 @@ static int encode_batch_regex(hutk_ctx* c, const uint8_t* bytes, const int64_t* 
     if (offsets[n_docs] > 0 && !bytes) return set_err(HUTK_E_ARG, "bad argument");
     for (int64_t i = 0; i < offsets[n_docs]; i++)  // (regexec would stop there; the packed interface refuses it anyway)
         if (!bytes[i]) return set_err(HUTK_E_NUL_BYTE, "a document contains a 0x00 byte");
-    std::vector<uint32_t> wbits, gbits;
+    std::vector<uint32_t> wbits, gbits, fbits, abits;
     std::vector<uint8_t> too_large;
-    int rc = regex_bitmaps(c->pattern, bytes, offsets, n_docs, wbits, gbits, too_large);
+    const bool pfx = c->tab.has_prefix;
+    int rc = regex_bitmaps(c->pattern, bytes, offsets, n_docs, wbits, gbits, too_large, pfx ? &fbits : nullptr, pfx ? &abits : nullptr);
     if (rc) return set_err(rc, "Regex could not be compiled.");
-    rc = encode_batch_host(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, &wbits, &gbits);
+    rc = encode_batch_host(c, bytes, offsets, n_docs, ids_out, ids_cap, out_offsets, status, &wbits, &gbits,
+                           pfx ? &fbits : nullptr, pfx ? &abits : nullptr);
     if (rc == HUTK_OK && status)
         for (int64_t d = 0; d < n_docs; d++)
             if (too_large[(size_t)d]) status[d] = HUTK_DOC_WORD_TOO_LARGE;
@@ -1221,7 +1282,8 @@ static int encode_batch_regex(hutk_ctx* c, const uint8_t* bytes, const int64_t* 
 
 static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* offsets, int64_t n_docs,
                              int32_t* ids_out, int64_t ids_cap, int64_t* out_offsets, int32_t* status,
-                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits) {
+                             const std::vector<uint32_t>* wbits, const std::vector<uint32_t>* gbits,
+                             const std::vector<uint32_t>* fbits, const std::vector<uint32_t>* abits) {
     if (!c) return set_err(HUTK_E_ARG, "ctx is NULL");
     if (c->host_only) return set_err(HUTK_E_DEVICE, "host-only context: no device to encode on");
     if (n_docs < 0 || !offsets || !out_offsets) return set_err(HUTK_E_ARG, "bad argument");
@@ -1282,7 +1344,7 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
     HIP_TRY(c->w_err.reserve(1));
     if (n_bytes) HIP_TRY(hipMemcpyAsync(c->s_bytes.p, bytes, (size_t)n_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->s_offsets.p, offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
-    const uint32_t *d_wb = nullptr, *d_gb = nullptr;
+    const uint32_t *d_wb = nullptr, *d_gb = nullptr, *d_fb = nullptr, *d_ab = nullptr;
     if (wbits) {
         HIP_TRY(c->w_wbits.reserve(wbits->size()));
         HIP_TRY(c->w_gbits.reserve(gbits->size()));
@@ -1290,9 +1352,17 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
         HIP_TRY(hipMemcpyAsync(c->w_gbits.p, gbits->data(), gbits->size() * 4, hipMemcpyHostToDevice, s));
         d_wb = c->w_wbits.p;
         d_gb = c->w_gbits.p;
+        if (fbits) {
+            HIP_TRY(c->w_fbits.reserve(fbits->size()));
+            HIP_TRY(c->w_abits.reserve(abits->size()));
+            HIP_TRY(hipMemcpyAsync(c->w_fbits.p, fbits->data(), fbits->size() * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(c->w_abits.p, abits->data(), abits->size() * 4, hipMemcpyHostToDevice, s));
+            d_fb = c->w_fbits.p;
+            d_ab = c->w_abits.p;
+        }
     }
     int rc = encode_device_impl(c, c->s_bytes.p, c->s_offsets.p, n_docs, n_bytes, c->s_ids.p, need,
-                                c->s_out_offsets.p, c->s_status.p, c->w_err.p, s, d_wb, d_gb);
+                                c->s_out_offsets.p, c->s_status.p, c->w_err.p, s, d_wb, d_gb, d_fb, d_ab);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_offsets, c->s_out_offsets.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
     int32_t err = 0;

@@ -134,6 +134,12 @@ struct BatchArgs {
     // stretch no match covers (no ids).  Both null: the hand-written splitter (the automaton in k_tiles).
     const uint32_t* word_bits;
     const uint32_t* gap_bits;
+    // ... together with a prefix (core.c:364-366, 421-451: the prefix goes with the FIRST MATCH of a document): bit p of
+    // first_bits = the word at byte p is its document's first match; of alone_bits = ... and the document begins with a
+    // space, so the prefix is encoded as a word of its own in front of it.  Both null: the first word is the one at the
+    // document's first byte.
+    const uint32_t* first_bits;
+    const uint32_t* alone_bits;
 };
 
 // ---- decode direction (hutk_decode.hip) ----

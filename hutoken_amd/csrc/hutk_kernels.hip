@@ -137,6 +137,16 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ void raise(int32_t* err, int32_t code) { atomicCAS(err, 0, code); }
 
+// Is the word at byte ws (of the document that starts at ds) the one the prefix goes with (core.c:364-366, 421-451: the
+// first word, or the first match of the regex pre-token path), and does its document begin with a space?
+__device__ __forceinline__ bool gbit(const uint32_t* m, int64_t p) { return (m[p >> 5] >> (p & 31)) & 1u; }
+__device__ __forceinline__ bool word_is_first(const BatchArgs& A, int64_t ws, int64_t ds) {
+    return A.first_bits ? gbit(A.first_bits, ws) : ws == ds;
+}
+__device__ __forceinline__ bool doc_begins_with_space(const BatchArgs& A, int64_t ws) {  // (for a first word)
+    return A.alone_bits ? gbit(A.alone_bits, ws) : A.bytes[ws] == ' ';
+}
+
 // ------------------------------------------------------------------------
 // splitter, restated per byte position (src/parser.c:24-183)
 // ------------------------------------------------------------------------
@@ -482,6 +492,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         wave_sync();
 
         // ---- 2. document starts inside the window -------------------------------
+        // (regex pre-token path with a prefix: the FIRST MATCHES of the documents instead, from the host's bitmap; the
+        // classifier, which needs the real starts, is not run on that path)
+        if (A.first_bits) {
+            if (lane < WINDOW / 32) {
+                const int64_t g = gw + 32 * lane;  // window bits [32 lane, 32 lane + 32); gw = 16 (mod 32), or -16 for tile 0
+                const int64_t w = g >> 5;          // (floor)
+                const uint32_t lo = w >= 0 ? A.first_bits[w] : 0u, hi = A.first_bits[w + 1];
+                docm[lane] = (lo >> 16) | (hi << 16);
+            }
+        } else
         for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
             const int64_t o = A.offsets[d];
             if (o >= gw + WINDOW) break;
@@ -638,7 +658,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 // regex pre-token path: text that no match covers is dropped (core.c:372-378 takes the LEFTMOST match at or
                 // after the cursor): such a stretch is a "word" without ids
                 const bool gap = A.gap_bits && ((A.gap_bits[(t0 + ws) >> 5] >> ((t0 + ws) & 31)) & 1u);
-                const bool pfx = !gap && T.has_prefix && docfirst && b0 != ' ';
+                const bool sp0 = A.alone_bits ? gbit(A.alone_bits, t0 + ws) : b0 == ' ';  // the document begins with a space
+                const bool pfx = !gap && T.has_prefix && docfirst && !sp0;
                 bool exc = !gap && (!known_end || nb > LANE_MAX_BYTES || (BYTE_MODE && T.has_prefix && docfirst));
                 if (MULTI && !gap && !exc) {
                     // an item whose replacement has several units, or none (pretokenizer.c:102-168 emits any string): the
@@ -1184,7 +1205,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     constexpr bool PREFIXED = !BYTE_MODE;  // arena words and prefix-alone ids exist in this mode only
     auto alone_ids = [&](int ws) -> uint32_t {  // prefix encoded as a word of its own (core.c:421-446)
         if (!PREFIXED || !T.has_prefix) return 0u;
-        return (bit_at(docm, ws + LOOKBACK) && sb[ws + LOOKBACK] == ' ') ? (uint32_t)T.n_prefix_alone : 0u;
+        if (!bit_at(docm, ws + LOOKBACK)) return 0u;
+        return (A.alone_bits ? gbit(A.alone_bits, t0 + ws) : sb[ws + LOOKBACK] == ' ') ? (uint32_t)T.n_prefix_alone : 0u;
     };
     auto arena_at = [&](int ws) -> int {
         if (PREFIXED)
@@ -1529,9 +1551,9 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
             const int64_t ws = rec.ws;
             const int nb = rec.len;
             d = doc_of(A, W, ws, rec.tile);
-            const bool docfirst = ws == A.offsets[d];
+            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
             const bool with_prefix = T.has_prefix && docfirst;
-            const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
+            const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
             gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
@@ -1726,9 +1748,9 @@ __device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& 
         if (have) {
             const int64_t ws = rec.ws;
             const int64_t d = doc_of(A, W, ws, rec.tile);
-            const bool docfirst = ws == A.offsets[d];
+            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
             const bool with_prefix = T.has_prefix && docfirst;
-            const bool alone = with_prefix && A.bytes[ws] == ' ';
+            const bool alone = with_prefix && doc_begins_with_space(A, ws);
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
             gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
@@ -1966,7 +1988,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
                 }
                 continue;
             }
-            const bool pfx_units = T.has_prefix && ws == ds && A.bytes[ws] != ' ';
+            const bool pfx_units = T.has_prefix && word_is_first(A, ws, ds) && !doc_begins_with_space(A, ws);
             const bool quad = T.is_byte_encoder && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
             if (lane == 0) {
                 W.exc[idx].len = (int32_t)nb;
@@ -2012,9 +2034,9 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         const int64_t ws = rec.ws;
         const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d];
         const int64_t nb = rec.len;
-        const bool docfirst = (ws == ds);
+        const bool docfirst = word_is_first(A, ws, ds);
         const bool with_prefix = T.has_prefix && docfirst;
-        const bool alone = with_prefix && A.bytes[ws] == ' ';  // core.c:365-366, 421-446
+        const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
         const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
         const int64_t gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);  // unit_scale slots per byte: room for an expanded word
 

@@ -143,3 +143,29 @@ def test_batch_threads_and_word_too_large(tmp_path, oracle_mod):
     # clears it again, so neither encode (lib.c:692-697) nor batch_encode (lib.c:796-808) reports it
     assert orc.encode(big) == r.encode(big) == r.encode("ab")
     assert r.batch_encode([big, "ab"], 2) == orc.batch_encode([big, "ab"], 2)
+
+
+def test_pattern_together_with_a_prefix(tmp_path, oracle_mod):
+    """The regex pre-token path with a prefix (core.c:362-366, 420-451: the prefix goes with the document's first MATCH)
+    and with replacements of several units, both shapes of vocabulary."""
+    import locale
+    if locale.setlocale(locale.LC_CTYPE, None) not in ("C.UTF-8", "C", "en_US.UTF-8"):
+        pytest.skip("POSIX regex matching depends on LC_CTYPE")
+    rng = random.Random(4242)
+    texts = [H.random_text(rng, max_words=rng.choice([3, 12, 40])) for _ in range(500)]
+    texts += ["", " ", "   x", "...abc", " ...abc def", "\n\nhello", " 123 abc"]
+    for kind in ("char", "byte"):
+        if kind == "char":
+            ents, sp = H.random_char_vocab(5, n_merges=400)
+            prefix, is_byte = "▁", False
+        else:
+            ents, sp = H.random_byte_vocab(15, n_merges=1200)
+            sp = dict(sp)
+            sp[ord("q")] = "qu"
+            prefix, is_byte = "Ġ", True
+        vp, spath = H.write_vocab(tmp_path, "rp" + kind, ents, sp)
+        for pat in ["[a-z]+", "[ ]?[[:alpha:]]+|[ ]?[[:digit:]]+", ".+", "[^ ]+", "x"]:
+            orc = oracle_mod.Oracle(vp, spath, prefix, is_byte, pattern=pat)
+            r = ref.RefTokenizer(vp, spath, prefix, is_byte, pattern=pat)
+            for t in texts:
+                assert orc.encode(t) == r.encode(t), (kind, pat, repr(t))

@@ -80,10 +80,25 @@ def test_gpu_equals_the_reference(g9, tmp_path, vg_files):
     orc = O.Oracle(vp, spath, None, True)
     ids, oo, st, rc = ctx.encode_packed(data, offs)
     assert [ids[oo[i]:oo[i + 1]].tolist() for i in range(len(texts))] == orc.batch_encode(texts, 4)
-    # the device-resident entry point cannot run libc's regexec
+    # the device-resident entry point brings the bytes down for libc's regexec and encodes on the device buffers
+    import torch
+    dev = torch.device("cuda", 0)
     ctx.set_pattern("[a-z]+")
-    with pytest.raises(ValueError, match="host"):
-        ctx.encode_device(0, 0, 0, 0, 0, 0, 0)
+    orc2 = O.Oracle(vp, spath, None, True, pattern="[a-z]+")
+    n = len(texts)
+    d_b, d_o = torch.from_numpy(np.array(data, copy=True)).to(dev), torch.from_numpy(np.array(offs, copy=True)).to(dev)
+    cap = ctx.ids_capacity(len(data), n)
+    d_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_oo = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.encode_device(d_b.data_ptr(), d_o.data_ptr(), n, len(data), d_ids.data_ptr(), cap, d_oo.data_ptr(), d_st.data_ptr(),
+                      d_err.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize(dev)
+    oo2 = d_oo.cpu().numpy()
+    ids2 = d_ids[: int(oo2[-1])].cpu().numpy()
+    assert int(d_err.item()) == 0
+    assert [ids2[oo2[i]:oo2[i + 1]].tolist() for i in range(n)] == orc2.batch_encode(texts, 4)
     # VG x C3 with the POSIX form of the GPT-2 pattern
     vp, sp, kw = vg_files
     ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
@@ -113,6 +128,35 @@ def test_gpu_against_the_oracle_long_words_and_gaps(tmp_path, g9):
         want = orc.batch_encode(texts, 4)
         got = [ids[oo[i]:oo[i + 1]].tolist() for i in range(len(texts))]
         assert rc == 0 and got == want, pat
+
+
+@pytest.mark.gpu
+def test_gpu_pattern_together_with_a_prefix(tmp_path):
+    """pattern= and prefix= (core.c:362-366, 420-451): the prefix goes with a document's FIRST MATCH -- in front of its units,
+    or, when the document begins with a space, as a word of its own before it -- wherever in the document that match is."""
+    from hutoken_amd import _capi
+    from oracle import oracle as O
+    rng = random.Random(91)
+    texts = [H.random_text(rng, max_words=rng.choice([3, 12, 60])) for _ in range(400)]
+    texts += ["", " ", "   x", "...abc", " ...abc def", "\n\nhello", "a" * 300, " " + "b" * 300, "123 abc", " 123 abc"]
+    for kind in ("char", "byte"):
+        if kind == "char":
+            ents, sp = H.random_char_vocab(5, n_merges=400)
+            prefix, is_byte = "▁", False
+        else:
+            ents, sp = H.random_byte_vocab(15, n_merges=1200)
+            prefix, is_byte = "Ġ", True
+        vp, spath = H.write_vocab(tmp_path, "rp" + kind, ents, sp)
+        ctx = _capi.Context(vp, spath, prefix, is_byte)
+        data, offs = O.pack(texts)
+        for pat in ["[a-z]+", "[ ]?[[:alpha:]]+|[ ]?[[:digit:]]+", ".+", "[^ ]+", "x"]:
+            ctx.set_pattern(pat)
+            orc = O.Oracle(vp, spath, prefix, is_byte, pattern=pat)
+            ids, oo, st, rc = ctx.encode_packed(data, offs)
+            want = orc.batch_encode(texts, 4)
+            got = [ids[oo[i]:oo[i + 1]].tolist() for i in range(len(texts))]
+            assert rc == 0 and got == want, (kind, pat, [i for i in range(len(texts)) if got[i] != want[i]][:5])
+        ctx.close()
 
 
 @pytest.mark.gpu
