@@ -129,6 +129,21 @@ __device__ __forceinline__ int ffbl_raw(uint32_t x) {
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// LDS byte address of a pointer into a __shared__ object (for the hand-issued reads below)
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+// Four 16-bit LDS reads IN FLIGHT TOGETHER.  Written out because the compiler, short of registers in k_tiles, gives the four
+// reads of the merge loop's scan one destination register and waits for each before it issues the next (seen in the ISA:
+// four LDS latencies per step where one would do).
+__device__ __forceinline__ void lds_read4_u16(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& v0, uint32_t& v1,
+                                              uint32_t& v2, uint32_t& v3) {
+    asm volatile(
+        "ds_read_u16 %0, %4\n\tds_read_u16 %1, %5\n\tds_read_u16 %2, %6\n\tds_read_u16 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+        : "memory");
+}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -293,11 +308,11 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
 //
 // Build switches: HUTK_TILE_WAVES tiles per workgroup (4; 2, 6, 8 and 16 measured no faster), HUTK_WAVES_EU resident
 // wavefronts per SIMD the byte-mode kernel is compiled for (8 = 64 VGPRs), HUTK_CHAR_EU the same outside byte-encoder
-// mode (6: LDS-limited).  Measurement-only switches: hutk_lab.h.  What was tried and dropped: DESIGN.md section 5.
+// mode (7: LDS-limited).  Measurement-only switches: hutk_lab.h.  What was tried and dropped: DESIGN.md section 5.
 // ------------------------------------------------------------------------
 constexpr int N_PHASE = 10;
 #ifndef HUTK_CHAR_EU
-#define HUTK_CHAR_EU 6
+#define HUTK_CHAR_EU 7
 #endif
 #ifndef HUTK_WAVES_EU
 #define HUTK_WAVES_EU 8
@@ -370,7 +385,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of the arena handed out
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
-    __shared__ uint8_t s_item_direct[BYTE_MODE ? 4 : 256];
+    __shared__ uint32_t s_item_direct[BYTE_MODE ? 1 : 8];  // one bit per lead byte (a byte each would cost a resident workgroup)
     // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
     // m[its offset + i]; a word gets its stretch of m when it enters the pool (a position-indexed array per tile
     // would be four times the size, and LDS is what limits the resident wavefronts).
@@ -396,7 +411,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     if (A.n_docs < 0) s_lab_pad[threadIdx.x] = 1;
 #endif
 
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // The wavefront's index is uniform, and told so the compiler keeps what derives from it in scalar registers: 6 vector
+    // registers fewer and no spill in byte-encoder mode (+1 %); outside it the extra scalar work costs 2 %, so not there.
+    const int lane = threadIdx.x & 63;
+    const int wv = BYTE_MODE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b works on
     // tile group (b % 8) * (groups / 8) + b / 8, so every XCD walks one contiguous eighth of the batch and the
     // lines two neighbouring tiles share (halo, lookback, offsets) meet in one L2.  The grid is a multiple of 8.
@@ -465,7 +483,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     if (!BYTE_MODE) {
         for (int i = threadIdx.x; i < 256; i += 64 * WAVES) {
             s_item_sym[i] = Sym<SymT>::narrow(T.item_sym[i]);
-            s_item_direct[i] = T.item_direct[i];
+            const unsigned long long direct = __ballot(T.item_direct[i] != 0);  // (a wavefront's 64 values of i are consecutive)
+            if (lane == 0) {
+                s_item_direct[i >> 5] = (uint32_t)direct;
+                s_item_direct[(i >> 5) + 1] = (uint32_t)(direct >> 32);
+            }
         }
     }
     __syncthreads();
@@ -771,7 +793,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                                 if (L == 1 || i + L > nb) { raise(A.err, HUTK_E_INVALID_UTF8); L = 1; }
                             }
                             uint32_t sym;
-                            if (s_item_direct[b]) sym = Sym<SymT>::widen(s_item_sym[b]);
+                            if ((s_item_direct[b >> 5] >> (b & 31u)) & 1u) sym = Sym<SymT>::widen(s_item_sym[b]);
                             else if (L == 1) sym = SYM_UNK;
                             else {
                                 uint32_t packed = b | ((uint32_t)sb[lw + i + 1] << 8);
@@ -882,6 +904,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 // ties (queue.c:162-164), so the best pair is one register and every comparison a v_min.
                 constexpr uint32_t NOKEY = 0xFFFFFFFFu;
                 uint32_t live = 0, cand = 0, best = NOKEY;
+                const uint32_t mw_lds = lds_addr(Mw);
                 auto scan_key = [&](uint32_t c) -> uint32_t {  // four candidates per step, their LDS reads in flight together
                     uint32_t b = NOKEY;
                     while (c) {
@@ -889,8 +912,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                         // holds (a word's stretch never starts at m[0], so that is a slot of this array)
                         const uint32_t c1 = c & (c - 1), c2 = c1 & (c1 - 1), c3 = c2 & (c2 - 1);
                         const int i0 = ffbl_raw(c), i1 = ffbl_raw(c1), i2 = ffbl_raw(c2), i3 = ffbl_raw(c3);
-                        const uint32_t k0 = ((uint32_t)Mw[i0] << 5) | (uint32_t)i0, k1 = ((uint32_t)Mw[i1] << 5) | (uint32_t)i1,
-                                       k2 = ((uint32_t)Mw[i2] << 5) | (uint32_t)i2, k3 = ((uint32_t)Mw[i3] << 5) | (uint32_t)i3;
+                        uint32_t m0, m1, m2, m3;
+                        lds_read4_u16(mw_lds + 2u * i0, mw_lds + 2u * i1, mw_lds + 2u * i2, mw_lds + 2u * i3, m0, m1, m2, m3);
+                        const uint32_t k0 = (m0 << 5) | (uint32_t)i0, k1 = (m1 << 5) | (uint32_t)i1,
+                                       k2 = (m2 << 5) | (uint32_t)i2, k3 = (m3 << 5) | (uint32_t)i3;
                         b = min(min(b, k0), min(min(k1, k2), k3));
                         c = c3 & (c3 - 1);
                     }

@@ -5,7 +5,7 @@ Prints JSON {opcode: count}; bench.py's issue model weights tools/valu_issue_ben
 import collections, json, os, re, subprocess, sys, tempfile
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "hutoken_amd", "csrc")
-want = sys.argv[1] if len(sys.argv) > 1 else "k_tilesItLb1ELb1ELi4EEE"
+want = sys.argv[1] if len(sys.argv) > 1 else "k_tilesItLb1ELb1ELi4ELb0EEE"
 out = os.path.join(tempfile.gettempdir(), "hutk_kernels_%d.s" % os.getuid())
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + csrc,
                        "--cuda-device-only", "-S", os.path.join(csrc, "hutk_kernels.hip"), "-o", out] + sys.argv[2:],
