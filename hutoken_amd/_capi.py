@@ -21,7 +21,7 @@ EXPORTS = [
     "hutk_encode_batch", "hutk_encode_batch_device", "hutk_encode", "hutk_vocab_size", "hutk_host_alloc",
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
-    "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_profile_raw", "hutk_debug_tile_bytes",
+    "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_long_words", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_profile_raw", "hutk_debug_tile_bytes",
     "hutk_debug_seam",
 ]
 
@@ -112,6 +112,9 @@ def load(build_if_missing=True):
     if hasattr(L, "hutk_debug_pairs_second"):  # (older builds under tools/ab.py lack it)
         L.hutk_debug_pairs_second.restype = i64
         L.hutk_debug_pairs_second.argtypes = [vp]
+    if hasattr(L, "hutk_debug_long_words"):
+        L.hutk_debug_long_words.restype = i64
+        L.hutk_debug_long_words.argtypes = [vp]
     if hasattr(L, "hutk_ctx_add_device"):
         L.hutk_ctx_add_device.restype = i32
         L.hutk_ctx_add_device.argtypes = [vp, i32]
@@ -277,7 +280,10 @@ class Context:
         out = np.zeros(8, dtype=np.int64)
         raise_for(load().hutk_table_stats(self._h, out.ctypes.data))
         keys = ["n_keys", "n_vocab_sym", "n_sym", "n_pairs", "pair_slots", "rank_is_sym", "ident_ids", "n_word_entries"]
-        return dict(zip(keys, out.tolist()))
+        d = dict(zip(keys, out.tolist()))
+        if hasattr(load(), "hutk_debug_long_words"):
+            d["n_long_word_entries"] = int(load().hutk_debug_long_words(self._h))
+        return d
 
     def seam_map(self):
         """-> (uint32[256], in use): bit y - 0xE0 of entry x set = some merge can join input bytes x | y."""

@@ -79,8 +79,7 @@ struct hutk_ctx {
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<WordSlot> d_word_tab;
-    DevBuf<WordSlotLong> d_wordl_tab;
-    int64_t n_word_entries = 0;
+    int64_t n_word_entries = 0, n_wordl_entries = 0;  // whole-word table entries in all, and those of the long-word companion
     DevBuf<uint64_t> d_bytepair32;  // {symbol, merged} as 32 + 32 bits
     DevBuf<long long> w_prof;
     bool profile = false;
@@ -236,7 +235,7 @@ int upload_tables(hutk_ctx* c) {
     D.bytepair = T.sym16 ? (const void*)c->d_bytepair16.p : (const void*)c->d_bytepair32.p;
     D.word_tab = nullptr;
     D.word_mask = 0;
-    D.wordl_tab = nullptr;
+    D.wordl_off = 0;
     D.wordl_mask = 0;
 
     // the prefix encoded as a word of its own (core.c:421-446) is a constant of the
@@ -376,7 +375,7 @@ void destroy(hutk_ctx* c) {
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
         c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release(); c->d_item_units.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
-        c->d_word_tab.release(); c->d_wordl_tab.release(); c->w_wbits.release(); c->w_gbits.release(); c->w_fbits.release(); c->w_abits.release();
+        c->d_word_tab.release(); c->w_wbits.release(); c->w_gbits.release(); c->w_fbits.release(); c->w_abits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
         c->w_exc.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
@@ -425,64 +424,67 @@ int build_word_table(hutk_ctx* c) {
     const int64_t key_bytes = T.sym16 ? WORD_KEY_BYTES_16 : WORD_KEY_BYTES_32;  // (WordSlot, hutk_device.h)
     std::vector<size_t> keep, keep_long;
     for (size_t i = 0; i < n; i++)
-        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2)
+        if (oo[i + 1] - oo[i] == 1 && ids[oo[i]] == T.sym_id[T.cand_sym[i]] && offs[i + 1] - offs[i] >= 2 &&
+            offs[i + 1] - offs[i] <= WORDL_KEY_BYTES)
             (offs[i + 1] - offs[i] <= key_bytes ? keep : keep_long).push_back(i);
-    auto key_of = [&](size_t i) {
-        uint32_t k[4] = {0, 0, 0, 0};
+    auto key_of = [&](size_t i, uint32_t* k) {  // the word's raw bytes as seven little-endian dwords, zero padded
+        for (int q = 0; q < 7; q++) k[q] = 0;
         const size_t len = (size_t)(offs[i + 1] - offs[i]);
         for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
-        return make_uint4(k[0], k[1], k[2], k[3]);
     };
-    if (!keep_long.empty() && !T.is_byte_encoder) {  // the companion table (WordSlotLong), see k_tiles for when it pays
-        std::vector<uint4> kk(keep_long.size());
-        for (size_t q = 0; q < keep_long.size(); q++) kk[q] = key_of(keep_long[q]);
-        // ONE slot per word (hash & mask), first come first served in vocabulary order; a word that finds its slot
-        // taken is left out and goes through the merge loop as before (the table is 8 x the words: about 1 in 17)
-        uint32_t cap = 256;
-        while (cap < keep_long.size() * 8 + 16) cap <<= 1;
-        std::vector<WordSlotLong> slots(cap + 1, WordSlotLong{{0, 0, 0, 0}, 0});
-        for (size_t j = 0; j < keep_long.size(); j++) {
+    // main table: two-choice cuckoo of 16-byte slots (hutk_device.h); a word that cannot be placed is simply left out
+    std::vector<WordSlot> slots(1, WordSlot{{0, 0, 0, 0}});
+    uint32_t cap = 0;
+    if (!keep.empty()) {
+        std::vector<uint4> kk(keep.size());
+        for (size_t q = 0; q < keep.size(); q++) {
+            uint32_t k[7];
+            key_of(keep[q], k);
+            kk[q] = make_uint4(k[0], k[1], k[2], k[3]);
+        }
+        cap = 1024;
+        while (cap < keep.size() * 5 / 2 + 16) cap <<= 1;
+        std::vector<uint32_t> where, homeless;
+        auto hash_of = [&](uint32_t j) { const uint4 k = kk[j]; return word_hash(k.x, k.y, k.z, k.w); };
+        cuckoo_place(keep.size(), cap, [&](uint32_t j) { return hash_of(j) & (cap - 1); },
+                     [&](uint32_t j) { return word_slot2(hash_of(j), cap - 1); }, where, &homeless);
+        slots.assign(cap + 1, WordSlot{{0, 0, 0, 0}});
+        for (size_t j = 0; j < keep.size(); j++) {
+            if (where[j] == 0xFFFFFFFFu) continue;
             const uint4 k = kk[j];
-            WordSlotLong& sl = slots[word_hash(k.x, k.y, k.z, k.w) & (cap - 1)];
-            if (sl.k[0] | sl.k[1] | sl.k[2] | sl.k[3]) continue;
-            sl = WordSlotLong{{k.x, k.y, k.z, k.w}, T.cand_sym[keep_long[j]]};
+            slots[where[j]] = T.sym16 ? WordSlot{{k.x, k.y, k.z, k.w | (T.cand_sym[keep[j]] << 16)}}
+                                      : WordSlot{{k.x, k.y, k.z, T.cand_sym[keep[j]]}};
             c->n_word_entries++;
         }
-        HIP_TRY(c->d_wordl_tab.reserve(slots.size()));
-        HIP_TRY(hipMemcpy(c->d_wordl_tab.p, slots.data(), slots.size() * sizeof(WordSlotLong), hipMemcpyHostToDevice));
-        c->dt.wordl_tab = c->d_wordl_tab.p;
-        c->dt.wordl_mask = cap - 1;
     }
-    if (keep.empty()) return HUTK_OK;
-    // two-choice cuckoo table of 16-byte slots (hutk_device.h); a word that cannot be placed is simply left out
-    std::vector<uint4> kk(keep.size());
-    for (size_t q = 0; q < keep.size(); q++) {
-        const size_t i = keep[q];
-        uint32_t k[4] = {0, 0, 0, 0};
-        const size_t len = (size_t)(offs[i + 1] - offs[i]);
-        for (size_t j = 0; j < len; j++) k[j >> 2] |= (uint32_t)T.cand_bytes[offs[i] + j] << (8 * (j & 3));
-        kk[q] = make_uint4(k[0], k[1], k[2], k[3]);
+    // the companion (WordSlotLong = two consecutive 16-byte slots behind the main table): ONE slot per word
+    // (word_hash_long & mask), first come first served in vocabulary order; a word that finds its slot taken is left out
+    // and goes through the merge loop as before (the table is 8 x the words: about 1 in 17)
+    uint32_t lcap = 0, loff = 0;
+    if (cap && !keep_long.empty() && !getenv("HUTK_NO_LONG_WORD_TABLE")) {
+        lcap = 256;
+        while (lcap < keep_long.size() * 8 + 16) lcap <<= 1;
+        loff = (uint32_t)slots.size();
+        loff += loff & 1u;  // (32-byte aligned)
+        slots.resize((size_t)loff + 2 * (size_t)lcap, WordSlot{{0, 0, 0, 0}});
+        for (size_t j = 0; j < keep_long.size(); j++) {
+            uint32_t k[7];
+            key_of(keep_long[j], k);
+            const size_t at = (size_t)loff + 2 * (size_t)(word_hash_long(k[0], k[1], k[2], k[3], k[4], k[5], k[6]) & (lcap - 1));
+            if (slots[at].k[0] | slots[at].k[1] | slots[at].k[2] | slots[at].k[3]) continue;
+            slots[at] = WordSlot{{k[0], k[1], k[2], k[3]}};
+            slots[at + 1] = WordSlot{{k[4], k[5], k[6], T.cand_sym[keep_long[j]]}};
+            c->n_word_entries++;
+            c->n_wordl_entries++;
+        }
     }
-    uint32_t cap = 1024;
-    while (cap < keep.size() * 5 / 2 + 16) cap <<= 1;
-    std::vector<uint32_t> where, homeless;
-    auto hash_of = [&](uint32_t j) { const uint4 k = kk[j]; return word_hash(k.x, k.y, k.z, k.w); };
-    cuckoo_place(keep.size(), cap, [&](uint32_t j) { return hash_of(j) & (cap - 1); },
-                 [&](uint32_t j) { return word_slot2(hash_of(j), cap - 1); }, where, &homeless);
-    std::vector<WordSlot> slots(cap + 1, WordSlot{{0, 0, 0, 0}});
-    size_t placed = 0;
-    for (size_t j = 0; j < keep.size(); j++) {
-        if (where[j] == 0xFFFFFFFFu) continue;
-        const uint4 k = kk[j];
-        slots[where[j]] = T.sym16 ? WordSlot{{k.x, k.y, k.z, k.w | (T.cand_sym[keep[j]] << 16)}}
-                                  : WordSlot{{k.x, k.y, k.z, T.cand_sym[keep[j]]}};
-        placed++;
-    }
+    if (!cap) return HUTK_OK;
     HIP_TRY(c->d_word_tab.reserve(slots.size()));
     HIP_TRY(hipMemcpy(c->d_word_tab.p, slots.data(), slots.size() * sizeof(WordSlot), hipMemcpyHostToDevice));
     c->dt.word_tab = c->d_word_tab.p;
     c->dt.word_mask = cap - 1;
-    c->n_word_entries += (int64_t)placed;
+    c->dt.wordl_off = loff;
+    c->dt.wordl_mask = lcap ? lcap - 1 : 0;
     return HUTK_OK;
 }
 
@@ -589,6 +591,7 @@ int hutk_uses_merges(const hutk_ctx* ctx) { return ctx && ctx->tab.id_path ? 1 :
 int64_t hutk_pair_table_entries(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs : 0; }
 int hutk_device_ordinal(const hutk_ctx* ctx) { return ctx ? ctx->device : -1; }
 int64_t hutk_debug_pairs_second(const hutk_ctx* ctx) { return ctx ? ctx->tab.n_pairs_second : 0; }
+int64_t hutk_debug_long_words(const hutk_ctx* ctx) { return ctx ? ctx->n_wordl_entries : 0; }
 int hutk_debug_seam(const hutk_ctx* ctx, uint32_t* out256) {
     if (!ctx || !out256) return set_err(HUTK_E_ARG, "bad argument");
     memcpy(out256, ctx->tab.seam_hi, sizeof ctx->tab.seam_hi);

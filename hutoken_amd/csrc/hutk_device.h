@@ -34,10 +34,12 @@ enum : uint8_t { C_INTERIOR = 0, C_ALPHA = 1, C_DIGIT = 2, C_OTHER = 3, C_SPACE 
 // k[3]; otherwise 12 key bytes, symbol = k[3].  (Round 2 began with 20-byte slots for 16-byte keys: two L1 accesses per
 // slot, and the kernel is bound by the number of gather accesses)
 struct WordSlot { uint32_t k[4]; };
-// ... and of its small companion for the words that do not fit (15..16 bytes; 13..16 with 32-bit symbols): 16 key bytes,
-// then the symbol.  Only the lanes that hold such a word load from it.
-struct WordSlotLong { uint32_t k[4]; uint32_t sym; };
-constexpr int WORD_KEY_BYTES_16 = 14, WORD_KEY_BYTES_32 = 12;
+// ... and of its companion for the words that do not fit (15..28 bytes; 13..28 with 32-bit symbols): 28 key bytes, then
+// the symbol: two 16-byte loads, which a lane that holds such a word issues INSTEAD of the two slot loads of the main
+// table (same registers, same instructions: the companion sits behind the main table in one allocation and a lane only
+// picks other offsets).
+struct WordSlotLong { uint32_t k[7]; uint32_t sym; };
+constexpr int WORD_KEY_BYTES_16 = 14, WORD_KEY_BYTES_32 = 12;  // (the companion: WORDL_KEY_BYTES, hutk_internal.h)
 
 struct DevTables {
     const uint4* pair_buckets;  // two entries per bucket {w0, w1, w0, w1}, see hutk_internal.h
@@ -63,8 +65,8 @@ struct DevTables {
     // slot 2 = word_slot2(hash, mask) (hutk_internal.h).  word_mask == 0: no table.
     const WordSlot* word_tab;
     uint32_t word_mask;
-    const WordSlotLong* wordl_tab;  // the companion for longer words: ONE slot per word, hash & wordl_mask; 0: none
-    uint32_t wordl_mask;
+    uint32_t wordl_off;   // the companion for longer words (WordSlotLong) begins at word_tab[wordl_off]: ONE slot per word,
+    uint32_t wordl_mask;  // word_hash_long & wordl_mask; wordl_mask == 0: none
     // the word splitter as an automaton (hutk_classify.h, namespace dfa): dfa::TABLE_BYTES of transition table, then
     // the 256-byte byte-class table; the same for every vocabulary, staged in LDS by k_tiles
     const uint4* split_dfa;

@@ -23,6 +23,7 @@ constexpr uint32_t SYM_BITS = 20;
 constexpr uint32_t SYM_UNK = (1u << SYM_BITS) - 1;  // unit that is no symbol: never merges, id -1
 constexpr uint32_t SYM_NONE = 0xFFFFFFFFu;          // "this pair has no rank"
 constexpr uint64_t SLOT_EMPTY = ~0ull;
+constexpr int WORDL_KEY_BYTES = 28;  // longest raw word the whole-word tables hold (the companion's key, hutk_device.h)
 
 // Pair table: BUCKETS of two 8-byte entries, one 16-byte load per lookup.  Entry (two dwords):
 //   w0 = left | (right & 0xFFF) << 20        w1 = right >> 12 | merged << 8 | filter nibble << 28
@@ -60,6 +61,10 @@ HUTK_HD uint32_t word_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
     uint32_t x = k0 ^ ((k1 << 13) | (k1 >> 19)) ^ ((k2 << 7) | (k2 >> 25)) ^ ((k3 << 21) | (k3 >> 11));
     x *= 0x9E3779B1u;
     return x ^ (x >> 15);
+}
+// ... and of a longer word (28 raw bytes, zero padded, as seven dwords): the same function with the upper dwords folded in
+HUTK_HD uint32_t word_hash_long(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t k4, uint32_t k5, uint32_t k6) {
+    return word_hash(k0 ^ ((k4 << 5) | (k4 >> 27)), k1 ^ ((k5 << 11) | (k5 >> 21)), k2 ^ ((k6 << 17) | (k6 >> 15)), k3);
 }
 // second candidate slot from the same hash: an odd multiple of its upper bits away from the first (never the same slot)
 HUTK_HD uint32_t word_slot2(uint32_t h, uint32_t mask) {

@@ -720,21 +720,35 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     k2 &= (uint32_t)mhi;
                     k3 &= (uint32_t)(mhi >> 32);
                 }
+                // A word of 15..28 bytes (13.. with 32-bit symbols) has the companion table: 28 key bytes and the symbol in two
+                // consecutive 16-byte slots behind the main table.  Its lane loads those two INSTEAD of the main table's two
+                // candidate slots -- same registers, same load instructions, other offsets --, so the round stays one
+                // memory round trip and the common lanes pay two selects.  (One choice: see build_word_table.)
+                const bool probe_long = !gap && !exc && !pfx && T.wordl_mask && nb > WORD_KEY && nb <= WORDL_KEY_BYTES;
+                uint32_t k4 = 0, k5 = 0, k6 = 0;
                 const uint32_t wh = word_hash(k0, k1, k2, k3);
-                const uint32_t h1 = probe ? wh & T.word_mask : 0u;
-                const uint32_t h2 = probe ? word_slot2(wh, T.word_mask) : 0u;
+                uint32_t o1 = probe ? wh & T.word_mask : 0u;  // slots to load (the table's first slot for a lane without a probe)
+                uint32_t o2 = probe ? word_slot2(wh, T.word_mask) : 0u;
+                if (__any(probe_long)) {  // (uniform)
+                    if (probe_long) {
+                        const int a = (ws + LOOKBACK) & ~3, o8 = 8 * ((ws + LOOKBACK) & 3);
+                        const uint32_t* sw = reinterpret_cast<const uint32_t*>(sb + a);
+                        const uint32_t q4 = sw[4], q5 = sw[5], q6 = sw[6], q7 = sw[7];
+                        const int nb2 = nb - 16;  // -3 .. 12 bytes beyond the first sixteen
+                        const uint64_t mlo = nb2 >= 8 ? ~0ull : nb2 <= 0 ? 0ull : ((1ull << (8 * nb2)) - 1ull);
+                        const uint32_t mhi = nb2 <= 8 ? 0u : nb2 >= 12 ? ~0u : ((1u << (8 * (nb2 - 8))) - 1u);
+                        k4 = funnel_r(q5, q4, o8) & (uint32_t)mlo;
+                        k5 = funnel_r(q6, q5, o8) & (uint32_t)(mlo >> 32);
+                        k6 = funnel_r(q7, q6, o8) & mhi;
+                        o1 = T.wordl_off + 2u * (word_hash_long(k0, k1, k2, k3, k4, k5, k6) & T.wordl_mask);
+                        o2 = o1 + 1u;
+                    }
+                }
                 uint4 s1 = make_uint4(0, 0, 0, 0), s2 = s1;
-                WordSlotLong l1{};
-                // (the companion table exists outside byte-encoder mode only: measured on C3 x VG it costs 1.4 % and finds
-                // next to nothing, on C5 x VL -- two-byte characters, longer words -- it is worth 13 %)
-                const bool probe_long = !BYTE_MODE && !gap && !exc && !pfx && T.wordl_mask && nb > WORD_KEY && nb <= 16;
                 uint32_t isym = 0;
                 if (T.word_mask) {  // uniform
-                    s1 = reinterpret_cast<const uint4*>(T.word_tab)[h1];
-                    s2 = reinterpret_cast<const uint4*>(T.word_tab)[h2];
-                }
-                if (!BYTE_MODE && T.wordl_mask && __any(probe_long)) {  // (uniform; many rounds have no such word)
-                    if (probe_long) l1 = T.wordl_tab[wh & T.wordl_mask];  // ONE choice: see build_word_table
+                    s1 = reinterpret_cast<const uint4*>(T.word_tab)[o1];
+                    s2 = reinterpret_cast<const uint4*>(T.word_tab)[o2];
                 }
                 if (BYTE_MODE) isym = T.item_sym[b0];
 #if HUTK_PERTURB_MEM
@@ -762,8 +776,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                     if (done) S[ws] = Sym<SymT>::narrow(KSH == 32 ? sw : sw >> (KSH & 31));
                 }
                 if (probe_long) {
-                    done = ((l1.k[0] ^ k0) | (l1.k[1] ^ k1) | (l1.k[2] ^ k2) | (l1.k[3] ^ k3)) == 0;
-                    if (done) S[ws] = Sym<SymT>::narrow(l1.sym);
+                    done = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2) | (s1.w ^ k3) | (s2.x ^ k4) | (s2.y ^ k5) | (s2.z ^ k6)) == 0;
+                    if (done) S[ws] = Sym<SymT>::narrow(s2.w);
                 }
                 int n = 0;
                 SymT* Sdst = S + ws;
@@ -1551,6 +1565,208 @@ __device__ __forceinline__ int64_t doc_of(const BatchArgs& A, const Workspace& W
 // take (unknown end, more than 64 units with a prefix) is left for k_exc, one wavefront per word.
 // ------------------------------------------------------------------------
 constexpr int MEDIUM_UNITS = 64;
+// A word of known length that d_exc_medium does not take (prefix units make it longer than MEDIUM_UNITS) goes straight on
+// k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
+__device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane) {
+    const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS)
+    const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
+    if (bq | bw) {
+        uint32_t aq = 0, aw = 0;
+        if (lane == 0) {
+            if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
+            if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
+        }
+        aq = __shfl(aq, 0, 64);
+        aw = __shfl(aw, 0, 64);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (to_quad) W.exc_quad[aq + __popcll(bq & below)] = (uint32_t)idx;
+        else if (leave) W.exc_wave[aw + __popcll(bw & below)] = (uint32_t)idx;
+    }
+}
+
+// The same for 16-bit symbols with rank == symbol order (GPT-2-shaped files, the id-keyed path): ONE DWORD PER UNIT,
+// merged symbol of (unit, next live unit) << 16 | symbol of the unit, in a row of the lane's own (MEDIUM_ROW dwords), so
+// that the search for the best pair reads FOUR units per LDS instruction and prices each with one v_and_or:
+// key = merged << 16 | position, smallest key = minimal rank, leftmost on ties (queue.c:162-164); a dead unit and a pair
+// without a rank read 0xFFFF in the upper half.  (The general form below looks its candidates up one by one through
+// 64-bit masks: ~10 instructions per candidate and trip, which on words of 33..62 letters was 4/5 of the kernel's time.)
+constexpr int MEDIUM_ROW = MEDIUM_UNITS + 4;  // dwords per lane: 16-byte aligned rows, lanes spread over the banks
+__device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                                  uint32_t vgrid, uint8_t* lds) {
+    const int lane = threadIdx.x;
+    uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + lane * MEDIUM_ROW;
+    constexpr uint32_t HI = 0xFFFF0000u;
+    const uint32_t n_exc = W.counters[0];
+    // 64 words at a time: the first lot by block index, further ones from a device cursor (counters[3]): words differ in
+    // their number of merges, and a fixed share per wavefront left the last ones running alone
+    for (uint32_t round = 0;; round++) {
+        uint32_t lot = vblock;
+        if (round) {
+            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[3], 1u);
+            lot = (uint32_t)__shfl((int)lot, 0, 64);
+        }
+        const uint64_t base = (uint64_t)lot * 64;
+        if (base >= n_exc || (int64_t)base >= W.cap_exc) break;
+        const uint64_t idx = base + lane;
+        bool have = idx < n_exc && (int64_t)idx < W.cap_exc;
+        ExcRec rec{};
+        if (have) rec = W.exc[idx];
+        have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
+        have = have && !T.has_multi;  // (items of several units: every exception word goes to d_exc, which expands them)
+        int64_t gbase = 0;
+        int n = 0, na = 0;
+        uint64_t live = 0;
+        uint32_t best = 0xFFFFFFFFu;
+        // best key of the lane's row: 16 bytes = four units per read, four reads in flight (the row reads "no rank" from
+        // the word's last unit to the next multiple of 16)
+        auto scan_row = [&](int nn) -> uint32_t {
+            uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+            for (int i = 0; i < nn; i += 16) {
+                uint4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const uint4*>(U + i + 4 * j);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t at = (uint32_t)(i + 4 * j);
+                    b0 = min(b0, min((v[j].x & HI) | at, (v[j].y & HI) | (at + 1u)));
+                    b1 = min(b1, min((v[j].z & HI) | (at + 2u), (v[j].w & HI) | (at + 3u)));
+                }
+            }
+            return min(b0, b1);
+        };
+        if (have) {
+            const int64_t ws = rec.ws;
+            const int nb = rec.len;
+            const int64_t d = doc_of(A, W, ws, rec.tile);
+            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
+            const bool with_prefix = T.has_prefix && docfirst;
+            const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
+            const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
+            na = alone ? T.n_prefix_alone : 0;
+            gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            if (kp + nb > MEDIUM_UNITS) {
+                have = false;  // k_exc
+            } else {
+                for (int i = 0; i < kp; i++) U[i] = HI | (T.prefix_syms[i] & 0xFFFFu);
+                n = kp;
+                int looked_up = 0;  // units [0, looked_up) still need their pair result from the pair table
+                if (T.is_byte_encoder) {
+                    // sixteen units per step: their bytes in flight together, then their (byte, next byte) table entries --
+                    // merged symbol of the pair << 16 | symbol of the byte: the row's dword as it is
+                    const uint8_t* wb = A.bytes + ws;
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
+                    for (int i0 = 0; i0 < nb; i0 += 16) {
+                        uint32_t b[17];
+#pragma unroll
+                        for (int j = 0; j < 17; j++) b[j] = wb[min(i0 + j, nb - 1)];  // (clamped: in bounds, no branch)
+                        uint32_t e[16];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) e[j] = bp[b[j] | (b[j + 1] << 8)];
+#pragma unroll
+                        for (int j = 0; j < 16; j++)
+                            if (i0 + j < nb) U[n + i0 + j] = (i0 + j + 1 < nb) ? e[j] : (e[j] | HI);
+                    }
+                    looked_up = n;  // (prefix units in front: their pairs, and the one into the word)
+                    n += nb;
+                } else {
+                    for (int i = 0; i < nb;) {
+                        const uint32_t b = A.bytes[ws + i];
+                        int L = (b < 0x80u) ? 1 : (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                        uint32_t sym;
+                        if ((b >= 0x80u && (L == 1 || b >= 0xF8u)) || i + L > nb) {
+                            raise(A.err, HUTK_E_INVALID_UTF8);
+                            sym = SYM_UNK;
+                            L = 1;
+                        } else if (T.item_direct[b]) {
+                            sym = T.item_sym[b];
+                        } else if (L == 1) {
+                            sym = SYM_UNK;
+                        } else {
+                            uint32_t packed = b | ((uint32_t)A.bytes[ws + i + 1] << 8);
+                            if (L > 2) packed |= (uint32_t)A.bytes[ws + i + 2] << 16;
+                            if (L > 3) packed |= (uint32_t)A.bytes[ws + i + 3] << 24;
+                            sym = char_lookup(T, packed);
+                        }
+                        U[n] = HI | (sym & 0xFFFFu);
+                        n++;
+                        i += L;
+                    }
+                    looked_up = n - 1;
+                }
+                for (int i0 = 0; i0 < looked_up; i0 += 4) {  // four lookups (eight loads) in flight
+                    PairProbe pr[4];
+                    uint32_t sy[5];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) sy[j] = (i0 + j < n) ? (U[i0 + j] & 0xFFFFu) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) sy[j] = sy[j] == 0xFFFFu ? SYM_UNK : sy[j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i0 + j < looked_up && i0 + j + 1 < n) {
+                            const uint32_t m = pair_resolve(T, pr[j], sy[j], sy[j + 1]);
+                            U[i0 + j] = (m << 16) | (sy[j] & 0xFFFFu);  // (SYM_NONE: 0xFFFF in the upper half)
+                        }
+                }
+                for (int i = n; i < ((n + 15) & ~15); i++) U[i] = 0xFFFFFFFFu;  // the row's last reads cover them
+                live = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+                best = scan_row(n);
+            }
+        }
+        // One merge per trip and lane: apply the best pair, issue the lookups of the two new neighbour pairs, search the
+        // row again while those loads fly (the pairs that change read "no rank" meanwhile), fold the two new keys in.
+        for (;;) {
+            const bool act = have && best < HI;
+            if (!__any(act)) break;
+            if (act) {
+                const int p = (int)(best & 63u);
+                const uint32_t merged = best >> 16;
+                const uint64_t above = live & ~((2ull << p) - 1ull);
+                const int q = __builtin_ctzll(above);  // the unit the merge consumes
+                live &= ~(1ull << q);
+                const uint64_t right = above & (above - 1ull);
+                const uint64_t left = live & ((1ull << p) - 1ull);
+                const int q2 = right ? __builtin_ctzll(right) : p;
+                const int p0 = left ? 63 - __builtin_clzll(left) : p;
+                const uint32_t ur = U[q2], ul = U[p0];
+                uint32_t sr = ur & 0xFFFFu, sl = ul & 0xFFFFu;
+                sr = sr == 0xFFFFu ? SYM_UNK : sr;  // (a unit that is no symbol: never a member of a pair)
+                sl = sl == 0xFFFFu ? SYM_UNK : sl;
+                const PairProbe pr = pair_issue(T, merged, sr), pl = pair_issue(T, sl, merged);  // both in flight
+                U[q] = 0xFFFFFFFFu;
+                U[p0] = ul | HI;      // (first: without a left neighbour p0 == p)
+                U[p] = HI | merged;
+                best = scan_row(n);
+                if (right) {
+                    const uint32_t m = pair_resolve(T, pr, merged, sr);
+                    U[p] = (m << 16) | merged;
+                    best = min(best, (m << 16) | (uint32_t)p);
+                }
+                if (left) {
+                    const uint32_t m = pair_resolve(T, pl, sl, merged);
+                    U[p0] = (m << 16) | (ul & 0xFFFFu);
+                    best = min(best, (m << 16) | (uint32_t)p0);
+                }
+            }
+        }
+        if (have) {
+            int32_t* out = W.exc_tok + gbase;
+            for (int i = 0; i < na; i++) out[i] = T.prefix_alone_ids[i];
+            int k = na;
+            for (uint64_t c = live; c; c &= c - 1) {
+                const uint32_t sy = U[__builtin_ctzll(c)] & 0xFFFFu;
+                out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
+            }
+            rec.cnt = (uint32_t)k;
+            rec.tok_base = gbase;
+            W.exc[idx] = rec;
+            atomicAdd(&W.tile_count[rec.tile], rec.cnt);
+        }
+        medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
+    }
+}
+
 template <typename SymT>
 __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
                                              uint32_t vgrid, uint8_t* lds) {
@@ -1570,7 +1786,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
         have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
         have = have && !T.has_multi;  // (items of several units: every exception word goes to d_exc, which expands them)
         int64_t d = 0, gbase = 0;
-        int n = 0, na = 0;
+        int n = 0, na = 0, pairs_to = 0;
         uint64_t live = 0, cand = 0;
         if (have) {
             const int64_t ws = rec.ws;
@@ -1588,7 +1804,32 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
                 for (int i = 0; i < kp; i++) Sm[i * 64 + lane] = Sym<SymT>::narrow(T.prefix_syms[i]);
                 n = kp;
                 if (T.is_byte_encoder) {
-                    for (int i = 0; i < nb; i++) Sm[(n + i) * 64 + lane] = Sym<SymT>::narrow(T.item_sym[A.bytes[ws + i]]);
+                    // sixteen units per step: their bytes in flight together, then their (byte, next byte) table entries --
+                    // {symbol of the byte, merged symbol of the pair}, as in k_tiles -- together: two round trips per step
+                    // instead of two per unit (a word of 47 letters: 6 instead of ~100)
+                    const uint8_t* wb = A.bytes + ws;
+                    const typename Sym<SymT>::Pair* bp = reinterpret_cast<const typename Sym<SymT>::Pair*>(T.bytepair);
+                    for (int i0 = 0; i0 < nb; i0 += 16) {
+                        uint32_t b[17];
+#pragma unroll
+                        for (int j = 0; j < 17; j++) b[j] = wb[min(i0 + j, nb - 1)];  // (clamped: in bounds, no branch)
+                        typename Sym<SymT>::Pair e[16];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) e[j] = bp[b[j] | (b[j + 1] << 8)];
+#pragma unroll
+                        for (int j = 0; j < 16; j++) {
+                            const int i = i0 + j;
+                            if (i < nb) {
+                                Sm[(n + i) * 64 + lane] = Sym<SymT>::pair_sym(e[j]);
+                                if (i + 1 < nb) {
+                                    const SymT mv = Sym<SymT>::pair_merged(e[j]);
+                                    Mm[(n + i) * 64 + lane] = mv;
+                                    if (mv != Sym<SymT>::NONE) cand |= 1ull << (n + i);
+                                }
+                            }
+                        }
+                    }
+                    pairs_to = n;  // (prefix units in front: their pairs, and the one into the word, are looked up below)
                     n += nb;
                 } else {
                     for (int i = 0; i < nb;) {
@@ -1615,7 +1856,9 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
                     }
                 }
                 live = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
-                for (int i0 = 0; i0 + 1 < n; i0 += 4) {  // four lookups (eight loads) in flight
+                // pair results by table lookup: all of them outside byte-encoder mode; in it only those with a prefix unit
+                // (units [0, pairs_to] as left members), the rest came with the (byte, next byte) entries
+                for (int i0 = 0; i0 + 1 < (T.is_byte_encoder ? pairs_to + 1 : n); i0 += 4) {  // four lookups (eight loads) in flight
                     PairProbe pr[4];
                     uint32_t sy[5];
 #pragma unroll
@@ -1624,7 +1867,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
                     for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (i0 + j + 1 < n) {
+                        if (i0 + j + 1 < n && (!T.is_byte_encoder || i0 + j < pairs_to)) {
                             const uint32_t m = pair_resolve(T, pr[j], sy[j], sy[j + 1]);
                             Mm[(i0 + j) * 64 + lane] = Sym<SymT>::narrow(m);
                             if (m != SYM_NONE) cand |= 1ull << (i0 + j);
@@ -1707,23 +1950,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        // A word of known length that is not taken here (prefix units make it longer than MEDIUM_UNITS) goes straight on
-        // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
-        const bool leave = !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0;
-        const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS)
-        const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
-        if (bq | bw) {
-            uint32_t aq = 0, aw = 0;
-            if (lane == 0) {
-                if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
-                if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
-            }
-            aq = __shfl(aq, 0, 64);
-            aw = __shfl(aw, 0, 64);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (to_quad) W.exc_quad[aq + __popcll(bq & below)] = (uint32_t)idx;
-            else if (leave) W.exc_wave[aw + __popcll(bw & below)] = (uint32_t)idx;
-        }
+        medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
     }
 }
 
@@ -2196,9 +2423,13 @@ constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUA
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 template <typename SymT>
 __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspace W, uint32_t n_medium) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds))];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds)),
+                                                             sizeof(SymT) == 2 ? 64 * MEDIUM_ROW * 4 : 0)];
     if (W.counters[0] == 0) return;  // no exception word in this batch
-    if (blockIdx.x < n_medium) d_exc_medium<SymT>(T, A, W, blockIdx.x, n_medium, lds);
+    if (blockIdx.x < n_medium) {
+        if (sizeof(SymT) == 2 && T.rank_is_sym) d_exc_medium_fast(T, A, W, blockIdx.x, n_medium, lds);
+        else d_exc_medium<SymT>(T, A, W, blockIdx.x, n_medium, lds);
+    }
     else d_exc_ends(T, A, W, blockIdx.x - n_medium, gridDim.x - n_medium, lds);
 }
 __global__ __launch_bounds__(64) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
@@ -2470,7 +2701,7 @@ __device__ __forceinline__ void d_doc_off(const BatchArgs& A, const Workspace& W
 
 // k_finish: everything behind the scan in ONE launch -- the workgroups [0, g_gather) copy tile runs to ids_out,
 // [g_gather, g_gather + g_exc) do the same for the tiles that also hold exception words, the rest write out_offsets.
-constexpr int FINISH_EXC_BLOCKS = 1024;
+constexpr int FINISH_EXC_BLOCKS = 2048;  // (18 KB of LDS each: eight per CU, 2048 resident)
 template <typename RunT>
 __global__ __launch_bounds__(64 * GATHER_WAVES) void k_finish(DevTables T, BatchArgs A, Workspace W, uint32_t g_gather) {
     const uint32_t b = blockIdx.x;

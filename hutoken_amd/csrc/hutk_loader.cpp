@@ -1062,7 +1062,7 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
             std::vector<std::string> us;
             for (size_t i = 0; i < order.size(); i++) {
                 const std::string& k = *order[i].second;
-                if (!split_units(k, true, us) || us.empty() || us.size() > 16) continue;
+                if (!split_units(k, true, us) || us.empty() || us.size() > (size_t)WORDL_KEY_BYTES) continue;
                 std::string raw;
                 bool ok = true;
                 for (auto& u : us) {
@@ -1074,7 +1074,7 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
                              (size_t)lead_len((unsigned char)u[0]) == u.size()) raw += u;
                     else { ok = false; break; }
                 }
-                if (!ok || raw.size() < 2 || raw.size() > 16) continue;
+                if (!ok || raw.size() < 2 || raw.size() > (size_t)WORDL_KEY_BYTES) continue;
                 T.cand_bytes.insert(T.cand_bytes.end(), raw.begin(), raw.end());
                 T.cand_off.push_back((uint32_t)T.cand_bytes.size());
                 T.cand_sym.push_back((uint32_t)i);

@@ -199,6 +199,9 @@ int hutk_last_timing(hutk_ctx* ctx, float* ms_tile_kernel, float* ms_total);
  * costs two loads instead of one). */
 int64_t hutk_debug_pairs_second(const hutk_ctx* ctx);
 
+/* Diagnostic: entries of the whole-word table's companion for words of 15..28 bytes (13..28 with 32-bit symbols). */
+int64_t hutk_debug_long_words(const hutk_ctx* ctx);
+
 /* Diagnostic: the seam map the tile kernel splits words by.  Bit (y - 0xE0) of out256[x] is set when some merge of
  * this vocabulary can join a token that ends with input byte x to one that begins with input byte y (0xE0..0xFF, the
  * lead bytes of three- and four-byte characters); where it is clear the reference's merge loop (src/core.c:66-209,

@@ -1,6 +1,6 @@
 """GPU parity at the edges of the device tables: vocabularies beyond 65519 symbols (32-bit symbols in LDS and in the tile
 runs, 12-byte keys in the whole-word table), and words whose length sits at the whole-word table's key limits (14 bytes
-with 16-bit symbols, 12 with 32-bit ones, 16 for the companion table outside byte-encoder mode).  Bit-exact against the
+with 16-bit symbols, 12 with 32-bit ones, 28 for the companion table).  Bit-exact against the
 oracle.  Needs a real MI355X."""
 import random
 
@@ -108,4 +108,70 @@ def test_word_lengths_at_the_table_key_limits(tmp_path, oracle_mod, is_byte):
     by_len = {n: v for n, v in by_len.items() if v}
     assert {13, 14, 15, 16} <= set(by_len), sorted(by_len)
     _same(ctx, orc, _docs_of_tokens(rng, toks, 6000, by_len), "key limits")
+    ctx.close()
+
+
+def _with_chains(ents, is_byte, rng, n_chains=400, lo=10, hi=31):
+    """The vocabulary plus chains of tokens that make long single-token WORDS: for a random word of capital consonants
+    (letters no other key holds) every prefix " B", " BC", " BCD", ... is a key, so the merge loop can only walk the chain
+    and the word ends as one token.  -> (entries, the words as raw bytes with their leading space)"""
+    from hutoken_amd import vocab_files as vf
+    t = vf.bytes_to_unicode()
+    have = {k for k, _ in ents}
+    nid = max(i for _, i in ents) + 1
+    out, words = list(ents), []
+    for _ in range(n_chains):
+        w = " " + "".join(rng.choice("BCDFGHJKLMPQRSVWXZ") for _ in range(rng.randint(lo, hi) - 1))
+        for k in range(2, len(w) + 1):
+            key = vf.encode_visible(w[:k].encode(), t) if is_byte else w[:k].replace(" ", "▁").encode("utf-8")
+            if key not in have:
+                have.add(key)
+                out.append((key, nid))
+                nid += 1
+        words.append(w.encode())
+    return out, words
+
+
+@pytest.mark.parametrize("is_byte", [True, False], ids=["byte-mode", "char-mode"])
+def test_long_words_of_the_companion_table(tmp_path, oracle_mod, is_byte, monkeypatch):
+    """Single-token words of 10..31 bytes: 15..28 bytes are the companion table's (two 16-byte slots behind the main
+    table, loaded by the word's lane instead of the main table's two candidate slots), 29 and more go through the merge
+    loop, and so does a table word with one letter changed.  With and without the companion the ids are the oracle's."""
+    rng = random.Random(13)
+    if is_byte:
+        ents, sp = H.random_byte_vocab(31, n_merges=3000, max_len=16)
+        prefix = None
+    else:
+        ents, sp = H.random_char_vocab(31, n_merges=3000, max_len=12)
+        prefix = "▁"
+    ents, words = _with_chains(ents, is_byte, rng)
+    assert {15, 16, 17, 27, 28, 29, 31} <= {len(w) for w in words}
+    vp, spath = H.write_vocab(tmp_path, "long", ents, sp)
+    orc = oracle_mod.Oracle(vp, spath, prefix, is_byte)
+    toks = [t for t in _raw_tokens(ents, is_byte) if b"\0" not in t and t.strip(b" \n\t")]
+    docs = []
+    for _ in range(6000):
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            r = rng.random()
+            w = rng.choice(words).strip()
+            if r < 0.5:
+                parts.append(w)
+            elif r < 0.65:  # one letter off: same hash input length, no entry
+                k = rng.randrange(len(w))
+                parts.append(w[:k] + bytes([rng.choice(b"BCDFGHJKLMPQRSVWXZ")]) + w[k + 1:])
+            elif r < 0.75:
+                parts.append(w[:rng.randint(1, len(w))])
+            else:
+                parts.append(rng.choice(toks).strip(b" \n\t") or b"x")
+        docs.append((b" " if rng.random() < 0.5 else b"") + b" ".join(parts))
+    ctx = _ctx(vp, spath, prefix, is_byte)
+    n_long = ctx.table_stats()["n_long_word_entries"]
+    assert n_long > 1000, n_long  # (400 chains x the prefixes of 15..28 bytes, minus the one-choice table's collisions)
+    _same(ctx, orc, docs, "companion table")
+    ctx.close()
+    monkeypatch.setenv("HUTK_NO_LONG_WORD_TABLE", "1")
+    ctx = _ctx(vp, spath, prefix, is_byte)
+    assert ctx.table_stats()["n_long_word_entries"] == 0
+    _same(ctx, orc, docs, "without the companion table")
     ctx.close()
