@@ -476,9 +476,31 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
     const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
-    for (int i = threadIdx.x; i < (dfa::TABLE_BYTES + 256) / 16; i += 64 * WAVES) {
-        const uint4 v = T.split_dfa[i];
-        reinterpret_cast<uint4*>(&s_m.c)[i] = v;  // table, then byte classes, as uploaded
+    // The tile's bytes are requested BEFORE the automaton's table is copied, and the offsets of its first documents before
+    // that copy is waited for: one memory round trip for the three instead of three in a row (the kernel is bound by
+    // the latency of its chains of dependent accesses).  A tile at either end of the data is staged
+    // byte by byte below.
+    static_assert(WINDOW / 16 > 64 && WINDOW / 16 <= 128, "two chunks per lane");
+    const bool whole = tile_ok && gw >= 0 && gw + WINDOW <= A.n_bytes;
+    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0;
+    if (whole) {
+        pre0 = *reinterpret_cast<const uint4*>(A.bytes + gw + 16 * lane);
+        if (lane < WINDOW / 16 - 64) pre1 = *reinterpret_cast<const uint4*>(A.bytes + gw + 16 * (lane + 64));
+    }
+    constexpr int DFA_CHUNKS = (dfa::TABLE_BYTES + 256) / 16;
+    static_assert(DFA_CHUNKS <= 2 * 64 * WAVES || WAVES < 4, "two chunks of the automaton's table per thread");
+    uint4 dfa0 = make_uint4(0, 0, 0, 0), dfa1 = dfa0;
+    if (WAVES >= 4) {
+        if ((int)threadIdx.x < DFA_CHUNKS) dfa0 = T.split_dfa[threadIdx.x];
+        if ((int)threadIdx.x + 64 * WAVES < DFA_CHUNKS) dfa1 = T.split_dfa[threadIdx.x + 64 * WAVES];
+    }
+    int64_t pre_o = 0;  // offsets[dfirst + lane]
+    if (tile_ok && !A.first_bits && dfirst + lane <= A.n_docs) pre_o = A.offsets[dfirst + lane];
+    if (WAVES >= 4) {
+        if ((int)threadIdx.x < DFA_CHUNKS) reinterpret_cast<uint4*>(&s_m.c)[threadIdx.x] = dfa0;  // table, then byte classes, as uploaded
+        if ((int)threadIdx.x + 64 * WAVES < DFA_CHUNKS) reinterpret_cast<uint4*>(&s_m.c)[threadIdx.x + 64 * WAVES] = dfa1;
+    } else {
+        for (int i = threadIdx.x; i < DFA_CHUNKS; i += 64 * WAVES) reinterpret_cast<uint4*>(&s_m.c)[i] = T.split_dfa[i];
     }
     if (!BYTE_MODE) {
         for (int i = threadIdx.x; i < 256; i += 64 * WAVES) {
@@ -495,6 +517,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         HUTK_STAMP(0);
 
         // ---- 1. stage bytes and tables ------------------------------------------------
+        if (whole) {
+            *reinterpret_cast<uint4*>(sb + 16 * lane) = pre0;
+            if (lane < WINDOW / 16 - 64) *reinterpret_cast<uint4*>(sb + 16 * (lane + 64)) = pre1;
+        } else
         for (int c = lane; c < WINDOW / 16; c += 64) {
             const int64_t p = gw + 16 * c;
             if (p >= 0 && p + 16 <= A.n_bytes) {
@@ -525,7 +551,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
         } else
         for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
-            const int64_t o = A.offsets[d];
+            const int64_t o = d == dfirst + lane ? pre_o : A.offsets[d];
             if (o >= gw + WINDOW) break;
             const int li = (int)(o - gw);
             if (li >= 0) atomicOr(&docm[li >> 5], 1u << (li & 31));
@@ -1355,7 +1381,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     }
     // ---- 8. ids emitted before each document that starts in this tile ----------
     for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
-        const int64_t o = A.offsets[d];
+        const int64_t o = A.offsets[d];  // (keeping the first ones from the start in registers: measured, no faster)
         if (o >= tile_end) break;
         if (o < t0) continue;
         const int r = (int)(o - t0);
