@@ -21,7 +21,8 @@ The JSON line also carries
                 `issue`: VALU wave-instructions per launch (committed PMC profile) x the MEASURED cost of a
                 wave-instruction (tools/valu_issue_bench.hip: 2 cycles for a few simple opcodes when two wavefronts
                 pair up, 4 for the rest; profiles/r03_issue_model.json prices the kernel's opcode mix) / (1024 SIMDs x
-                the launch's cycles): a range, from "every simple opcode pairs" to "none does"
+                the launch's cycles): a range, from "every simple opcode pairs" to "none does" -- an upper estimate;
+                `latency`: what does bind the kernel (occupancy A/B, L2 latency counters: profiles/r03_latency.json)
   strong        (N > 1) BASELINE config 4: the SAME 1,000,000 documents cut into N byte-balanced
                 contiguous shards (hutoken_amd.sharding.shard_by_bytes), rank r generating only its range
   end_to_end    (N = 1) the drop-in's host entry points on the same workload: page-locked host buffers in
@@ -479,9 +480,21 @@ def main():
                 "source": iss_src, "cost_model": "profiles/r03_issue_model.json",
                 "note": "share of the launch's SIMD cycles spent issuing VALU work, as a range: on gfx950 a wave64 VALU "
                         "instruction costs 2 cycles for a few simple opcodes when two wavefronts pair up and 4 otherwise "
-                        "(measured, tools/valu_issue_bench.hip); low end = every simple opcode of the kernel's mix pairs, "
-                        "high end = none does.  Neither issue nor HBM alone binds k_tiles: +30 % VALU, +27 % wavefront "
-                        "life time and +22 % table gathers each cost 10-13 % (profiles/r03_ab_perturb.txt)"}
+                        "(measured on homogeneous streams, tools/valu_issue_bench.hip); low end = every simple opcode of the "
+                        "kernel's mix pairs, high end = none does.  An UPPER estimate, not the binding limit: with 7 instead of "
+                        "8 resident workgroups per CU the kernel loses 12 % (see `latency`), which a saturated issue port "
+                        "would not show"}
+        # What binds: the latency of chains of dependent table gathers (measured, profiles/r03_latency.json).
+        try:
+            lat = json.load(open(os.path.join(ROOT, "profiles", "r03_latency.json")))
+            line["roofline"]["latency"] = {
+                "bound": lat["bound"], "occupancy_ab_gbs": lat["occupancy_ab_gbs"],
+                "wait_frac_profiled": iss.get("wait_any_frac") if iss else None,
+                "mean_l1_to_l2_read_latency_cycles": lat["memory_latency_pmc"]["mean_l1_to_l2_read_latency_cycles"],
+                "mean_l2_miss_latency_cycles": lat["memory_latency_pmc"]["mean_l2_miss_to_fabric_latency_cycles"],
+                "l2_hit_rate": lat["memory_latency_pmc"]["l2_hit_rate"], "source": "profiles/r03_latency.json"}
+        except Exception:
+            pass
         if world > 1:
             line["weak"] = mode_line(modes["weak"])
             line["strong"] = dict(mode_line(modes["strong"]),
