@@ -384,6 +384,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     constexpr bool FAST_TRIPS = RANK_IS_SYM && sizeof(SymT) == 2;
     __shared__ Tile L[WAVES];
     __shared__ uint32_t pool_cnt[3];  // long words, other words, entries of the arena handed out
+    // Exception records and places on k_gather_exc's list are claimed per WORKGROUP (one 64-bit atomic for its tiles, in the
+    // shadow of the merge phase's barriers), not per tile: a batch full of exception words was bound by those same-address
+    // atomics (100 k of them at ~12 ns: 1.2 ms for 97 MB of 33-62-letter words).  s_exc_cnt: records | tiles << 16 of
+    // the workgroup's tiles, s_exc_base: what the atomic returned.
+    __shared__ uint32_t s_exc_cnt;
+    __shared__ unsigned long long s_exc_base;
     __shared__ SymT s_item_sym[BYTE_MODE ? 2 : 256];      // non-byte mode only: lead byte -> symbol
     __shared__ uint32_t s_item_direct[BYTE_MODE ? 1 : 8];  // one bit per lead byte (a byte each would cost a resident workgroup)
     // Merge phase: the pool of words and m, the pair results of units (i, next live) of a pooled word at
@@ -512,7 +518,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
         }
     }
+    if (threadIdx.x == 0) s_exc_cnt = 0;
     __syncthreads();
+    uint32_t my_exc_off = 0;  // my tile's share of the workgroup's claim: records before mine | tiles before mine << 16
     if (tile_ok) {
         HUTK_STAMP(0);
 
@@ -869,6 +877,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             wave_sync();
         }
         HUTK_STAMP(4);
+        {   // exception words of my tile (excm is final here): my share of the workgroup's claim
+            const uint32_t e16 = reinterpret_cast<const uint16_t*>(excm)[lane];
+            if (__any(e16 != 0)) {  // (rare)
+                uint32_t tot;
+                (void)wave_excl_scan((uint32_t)__popc(e16), lane, &tot);
+                uint32_t off = 0;
+                if (lane == 0) off = atomicAdd(&s_exc_cnt, tot | (1u << 16));
+                my_exc_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+            }
+        }
 
     }
 
@@ -894,6 +912,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 #endif
         if (threadIdx.x == 0) { pool_cnt[0] = 0; pool_cnt[1] = 0; pool_cnt[2] = FAST_TRIPS ? 2u : 0u; }  // (see scan_key: m[0..1] stay free)
         __syncthreads();  // (also: every wavefront is done with the automaton, whose LDS the merge arrays reuse)
+        if (first_epoch && threadIdx.x == 0 && s_exc_cnt != 0) {  // (every wavefront has added its tile's count; read after the next barrier)
+            const uint32_t cnt = s_exc_cnt;
+            s_exc_base = atomicAdd(reinterpret_cast<unsigned long long*>(W.counters),
+                                   ((unsigned long long)(cnt >> 16) << 32) | (unsigned long long)(cnt & 0xFFFFu));
+        }
         if (first_epoch) HUTK_MSTAMP(1);
         uint32_t pending = 0;
         if (tile_ok) {
@@ -1302,13 +1325,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     uint32_t exc_first = 0;
     if (lane == 0) {
         if (n_exc) {
-            // one 64-bit atomic claims the tile's exception records (low word, counters[0]) and its place on
-            // k_gather_exc's work list (high word, counters[1]): same-address atomics are what a batch full of
-            // exception words is bound by
-            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(W.counters),
-                                                     (1ull << 32) | (unsigned long long)n_exc);
-            exc_first = (uint32_t)old;
-            W.exc_tiles[(uint32_t)(old >> 32)] = (uint32_t)tile;
+            // the tile's exception records (counters[0]) and its place on k_gather_exc's work list (counters[1]): my share
+            // of what the workgroup claimed with one 64-bit atomic
+            const unsigned long long old = s_exc_base;
+            exc_first = (uint32_t)old + (my_exc_off & 0xFFFFu);
+            W.exc_tiles[(uint32_t)(old >> 32) + (my_exc_off >> 16)] = (uint32_t)tile;
         }
         W.tile_count[tile] = n_dense;
         W.tile_dense[tile] = n_dense;
