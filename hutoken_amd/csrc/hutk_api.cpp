@@ -323,7 +323,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + n_tiles / 32 + 16));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
-    HIP_TRY(c->w_counters.reserve(8));
+    HIP_TRY(c->w_counters.reserve(16));
     HIP_TRY(c->w_err.reserve(1));
     // exception words: longer than a lane takes (more than LANE_MAX_UNITS bytes), first of their document, or cut off by
     // a tile's budget -- unless items of several units make ANY word one (then: at most a word per byte)

@@ -113,7 +113,7 @@ struct Workspace {
     ExcRec* exc;               // [cap_exc]
     uint32_t* exc_quad;        // [cap_exc] exception words of at most 256 units for d_exc_quad (count: counters[4])
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in d_exc (count: counters[5])
-    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] exception work cursor, [3] records left for k_exc, [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
+    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] d_exc's work cursor, [3] d_exc_lane_fast<1>'s (k_exc_a), [8] d_exc_lane_fast<4>'s (k_exc_b), [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
     uint32_t* noreal_bits;     // [n_tiles / 32 + 1] bit t: tile t holds no word start of the reference's own (k_cut)
     uint32_t* tile_lastreal;   // [n_tiles] position of the tile's last such start | ids before it << 16 (written when none follows in the halo)

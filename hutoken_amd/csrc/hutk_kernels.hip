@@ -285,7 +285,7 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
     // what the kernels behind this one add to or publish in: error word, counters, per-document status, scan states
     // (here rather than in memsets of their own: a batch is a handful of launches)
     if (t == 0) *A.err = 0;
-    if (t < 8) W.counters[t] = 0;
+    if (t < 16) W.counters[t] = 0;
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     if (A.status)
         for (int64_t d = t; d < A.n_docs; d += n_threads) A.status[d] = 0;
@@ -1612,10 +1612,11 @@ __device__ __forceinline__ int64_t doc_of(const BatchArgs& A, const Workspace& W
 // take (unknown end, more than 64 units with a prefix) is left for k_exc, one wavefront per word.
 // ------------------------------------------------------------------------
 constexpr int MEDIUM_UNITS = 64;
+constexpr int QUAD_UNITS = 256;  // longest word of k_exc_b's quad list (d_exc_quad, d_exc_lane_fast<4>)
 // A word of known length that d_exc_medium does not take (prefix units make it longer than MEDIUM_UNITS) goes straight on
 // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
 __device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane) {
-    const bool to_quad = leave && T.is_byte_encoder && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS)
+    const bool to_quad = leave && (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS; outside byte-encoder mode the list is d_exc_lane_fast<4>'s only)
     const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
     if (bq | bw) {
         uint32_t aq = 0, aw = 0;
@@ -1637,32 +1638,84 @@ __device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace
 // key = merged << 16 | position, smallest key = minimal rank, leftmost on ties (queue.c:162-164); a dead unit and a pair
 // without a rank read 0xFFFF in the upper half.  (The general form below looks its candidates up one by one through
 // 64-bit masks: ~10 instructions per candidate and trip, which on words of 33..62 letters was 4/5 of the kernel's time.)
+//
+// NW = 1: the words d_exc_medium takes (up to 64 units, straight from the exception records, 64 words per wavefront).
+// NW = 2, 4: the words of k_exc_quad's list (up to QUAD_UNITS = 256 units, lengths found by d_exc_ends): those of up to 128
+// units SIXTEEN per wavefront in rows of 132 dwords, the longer ones EIGHT per wavefront in rows of 260, liveness in two /
+// four 64-bit words.  A quarter / an eighth of the lanes work -- in 8.4 KB of LDS, so that k_exc_b's other role keeps its
+// resident wavefronts -- and still do more words per microsecond than d_exc_quad's sixteen lanes per word, whose every
+// trip pays a DPP reduction and a chain of cross-lane shuffles to find the neighbours.
 constexpr int MEDIUM_ROW = MEDIUM_UNITS + 4;  // dwords per lane: 16-byte aligned rows, lanes spread over the banks
-__device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
-                                                  uint32_t vgrid, uint8_t* lds) {
+template <int NW>
+struct LiveBits {  // units still alive, 64 per word
+    uint64_t w[NW];
+    __device__ __forceinline__ void init(int n) {
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = n >= 64 * (k + 1) ? ~0ull : n > 64 * k ? ((1ull << (n - 64 * k)) - 1ull) : 0ull;
+    }
+    __device__ __forceinline__ void clear(int q) {
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            if ((q >> 6) == k) w[k] &= ~(1ull << (q & 63));
+    }
+    __device__ __forceinline__ int next_after(int p) const {  // first live unit behind p, or -1
+        int r = -1;
+#pragma unroll
+        for (int k = NW - 1; k >= 0; k--) {
+            const int pk = p - 64 * k;
+            uint64_t m = w[k];
+            if (pk >= 63) m = 0;
+            else if (pk >= 0) m &= ~((2ull << pk) - 1ull);
+            if (m) r = 64 * k + __builtin_ctzll(m);
+        }
+        return r;
+    }
+    __device__ __forceinline__ int prev_before(int p) const {  // last live unit in front of p, or -1
+        int r = -1;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const int pk = p - 64 * k;
+            uint64_t m = w[k];
+            if (pk <= 0) m = 0;
+            else if (pk < 64) m &= (1ull << pk) - 1ull;
+            if (m) r = 64 * k + 63 - __builtin_clzll(m);
+        }
+        return r;
+    }
+};
+template <int NW, int LANES>
+__device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                                uint32_t vgrid, uint8_t* lds) {
+    constexpr int UNITS = 64 * NW, ROW = UNITS + 4;
+    static_assert(UNITS <= QUAD_UNITS, "the quad list holds words of up to QUAD_UNITS units");
     const int lane = threadIdx.x;
-    uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + lane * MEDIUM_ROW;
+    uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + (lane % LANES) * ROW;
     constexpr uint32_t HI = 0xFFFF0000u;
-    const uint32_t n_exc = W.counters[0];
+    const uint32_t n_exc = NW == 1 ? W.counters[0] : W.counters[4];  // records, or entries of the quad list
     // 64 words at a time: the first lot by block index, further ones from a device cursor (counters[3]): words differ in
     // their number of merges, and a fixed share per wavefront left the last ones running alone
     for (uint32_t round = 0;; round++) {
         uint32_t lot = vblock;
         if (round) {
-            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[3], 1u);
+            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[NW == 1 ? 3 : NW == 2 ? 8 : 9], 1u);
             lot = (uint32_t)__shfl((int)lot, 0, 64);
         }
-        const uint64_t base = (uint64_t)lot * 64;
-        if (base >= n_exc || (int64_t)base >= W.cap_exc) break;
-        const uint64_t idx = base + lane;
-        bool have = idx < n_exc && (int64_t)idx < W.cap_exc;
+        const uint64_t base = (uint64_t)lot * LANES;
+        if (base >= n_exc || (NW == 1 && (int64_t)base >= W.cap_exc)) break;
+        const uint64_t at = base + lane;
+        bool have = lane < LANES && at < n_exc && (NW > 1 || (int64_t)at < W.cap_exc);
+        uint64_t idx = at;  // the word's exception record
+        if (NW > 1 && have) idx = W.exc_quad[at];
         ExcRec rec{};
         if (have) rec = W.exc[idx];
-        have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
-        have = have && !T.has_multi;  // (items of several units: every exception word goes to d_exc, which expands them)
+        if (NW == 1) {
+            have = have && rec.len >= 1 && rec.len <= LANE_MAX_BYTES && rec.cnt == 0;
+            have = have && !T.has_multi;  // (items of several units: every exception word goes to d_exc, which expands them)
+        }
         int64_t gbase = 0;
         int n = 0, na = 0;
-        uint64_t live = 0;
+        LiveBits<NW> live;
+        live.init(0);
         uint32_t best = 0xFFFFFFFFu;
         // best key of the lane's row: 16 bytes = four units per read, four reads in flight (the row reads "no rank" from
         // the word's last unit to the next multiple of 16)
@@ -1691,8 +1744,8 @@ __device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const Batc
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
             gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
-            if (kp + nb > MEDIUM_UNITS) {
-                have = false;  // k_exc
+            if (kp + nb > UNITS || (NW == 4 && kp + nb <= UNITS / 2)) {
+                have = false;  // NW == 1: k_exc's or the quad list's; NW == 2: left to the NW == 4 pass; NW == 4: the NW == 2 pass took it
             } else {
                 for (int i = 0; i < kp; i++) U[i] = HI | (T.prefix_syms[i] & 0xFFFFu);
                 n = kp;
@@ -1757,7 +1810,7 @@ __device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const Batc
                         }
                 }
                 for (int i = n; i < ((n + 15) & ~15); i++) U[i] = 0xFFFFFFFFu;  // the row's last reads cover them
-                live = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+                live.init(n);
                 best = scan_row(n);
             }
         }
@@ -1767,15 +1820,14 @@ __device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const Batc
             const bool act = have && best < HI;
             if (!__any(act)) break;
             if (act) {
-                const int p = (int)(best & 63u);
+                const int p = (int)(best & 0xFFFFu);
                 const uint32_t merged = best >> 16;
-                const uint64_t above = live & ~((2ull << p) - 1ull);
-                const int q = __builtin_ctzll(above);  // the unit the merge consumes
-                live &= ~(1ull << q);
-                const uint64_t right = above & (above - 1ull);
-                const uint64_t left = live & ((1ull << p) - 1ull);
-                const int q2 = right ? __builtin_ctzll(right) : p;
-                const int p0 = left ? 63 - __builtin_clzll(left) : p;
+                const int q = live.next_after(p);  // the unit the merge consumes (there is one: the pair was a candidate)
+                live.clear(q);
+                const int qn = live.next_after(p), pn = live.prev_before(p);
+                const bool right = qn >= 0, left = pn >= 0;
+                const int q2 = right ? qn : p;
+                const int p0 = left ? pn : p;
                 const uint32_t ur = U[q2], ul = U[p0];
                 uint32_t sr = ur & 0xFFFFu, sl = ul & 0xFFFFu;
                 sr = sr == 0xFFFFu ? SYM_UNK : sr;  // (a unit that is no symbol: never a member of a pair)
@@ -1801,16 +1853,18 @@ __device__ __forceinline__ void d_exc_medium_fast(const DevTables& T, const Batc
             int32_t* out = W.exc_tok + gbase;
             for (int i = 0; i < na; i++) out[i] = T.prefix_alone_ids[i];
             int k = na;
-            for (uint64_t c = live; c; c &= c - 1) {
-                const uint32_t sy = U[__builtin_ctzll(c)] & 0xFFFFu;
-                out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
-            }
+#pragma unroll
+            for (int j = 0; j < NW; j++)
+                for (uint64_t c = live.w[j]; c; c &= c - 1) {
+                    const uint32_t sy = U[64 * j + __builtin_ctzll(c)] & 0xFFFFu;
+                    out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
+                }
             rec.cnt = (uint32_t)k;
             rec.tok_base = gbase;
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
+        if (NW == 1) medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
     }
 }
 
@@ -2008,7 +2062,6 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
 // (no compaction), and only the lanes whose pairs changed rescan.  A merge costs one round trip of pair
 // lookups for four words at once instead of ~2 us for one word in k_exc.
 // ------------------------------------------------------------------------
-constexpr int QUAD_UNITS = 256;
 __device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {  // minimum over each row of 16 lanes, in every lane
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
@@ -2288,7 +2341,7 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
                 continue;
             }
             const bool pfx_units = T.has_prefix && word_is_first(A, ws, ds) && !doc_begins_with_space(A, ws);
-            const bool quad = T.is_byte_encoder && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
+            const bool quad = (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
             if (lane == 0) {
                 W.exc[idx].len = (int32_t)nb;
                 if (quad) lq[nq] = idx; else lw[nw] = idx;
@@ -2474,16 +2527,29 @@ __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspac
                                                              sizeof(SymT) == 2 ? 64 * MEDIUM_ROW * 4 : 0)];
     if (W.counters[0] == 0) return;  // no exception word in this batch
     if (blockIdx.x < n_medium) {
-        if (sizeof(SymT) == 2 && T.rank_is_sym) d_exc_medium_fast(T, A, W, blockIdx.x, n_medium, lds);
+        if (sizeof(SymT) == 2 && T.rank_is_sym) d_exc_lane_fast<1, 64>(T, A, W, blockIdx.x, n_medium, lds);
         else d_exc_medium<SymT>(T, A, W, blockIdx.x, n_medium, lds);
     }
     else d_exc_ends(T, A, W, blockIdx.x - n_medium, gridDim.x - n_medium, lds);
 }
+// FAST: 16-bit symbols with rank == symbol order: the quad list goes to d_exc_lane_fast (one lane per word: first the words
+// of up to 128 units, then the longer ones) instead of d_exc_quad
+constexpr size_t LANE_FAST_LDS = cmax(16 * (128 + 4) * 4, 8 * (256 + 4) * 4);
+template <bool FAST>
 __global__ __launch_bounds__(64) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4)];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4), FAST ? LANE_FAST_LDS : 0)];
     if (W.counters[0] == 0) return;
-    if (blockIdx.x < (uint32_t)EXB_QUAD) d_exc_quad(T, A, W, blockIdx.x, EXB_QUAD, lds);
-    else d_exc(T, A, W, blockIdx.x - EXB_QUAD, EXB_WAVE, lds);
+    if (blockIdx.x < (uint32_t)EXB_QUAD) {
+        if (FAST) {
+            d_exc_lane_fast<2, 16>(T, A, W, blockIdx.x, EXB_QUAD, lds);
+            wave_sync();
+            d_exc_lane_fast<4, 8>(T, A, W, blockIdx.x, EXB_QUAD, lds);
+        } else {
+            d_exc_quad(T, A, W, blockIdx.x, EXB_QUAD, lds);
+        }
+    } else {
+        d_exc(T, A, W, blockIdx.x - EXB_QUAD, EXB_WAVE, lds);
+    }
 }
 
 // one-off: merge a short symbol sequence (the prefix encoded as its own word)
@@ -2892,19 +2958,28 @@ __global__ __launch_bounds__(CUT_THREADS) void k_cut(DevTables T, BatchArgs A, W
 constexpr int SMALL_TILES = 32;
 template <typename SymT>
 __global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds)),
-                                                             cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4))];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(cmax(2 * MEDIUM_UNITS * 64 * sizeof(SymT), sizeof(EndsLds)),
+                                                                  cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4)),
+                                                             sizeof(SymT) == 2 ? cmax(64 * MEDIUM_ROW * 4, LANE_FAST_LDS) : 0)];
     const int lane = threadIdx.x;
+    const bool fast = sizeof(SymT) == 2 && T.rank_is_sym;  // (as in k_exc_a / k_exc_b: the quad list may hold words of any mode then)
     auto stage_done = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
         __syncthreads();
     };
     if (W.counters[0] != 0) {  // exception words
-        d_exc_medium<SymT>(T, A, W, 0, 1, lds);
+        if (fast) d_exc_lane_fast<1, 64>(T, A, W, 0, 1, lds);
+        else d_exc_medium<SymT>(T, A, W, 0, 1, lds);
         stage_done();
         for (uint32_t sub = 0; sub < ENDS_SHARE; sub++) d_exc_ends(T, A, W, sub, ENDS_SHARE, lds);
         stage_done();
-        d_exc_quad(T, A, W, 0, 1, lds);
+        if (fast) {
+            d_exc_lane_fast<2, 16>(T, A, W, 0, 1, lds);
+            stage_done();
+            d_exc_lane_fast<4, 8>(T, A, W, 0, 1, lds);
+        } else {
+            d_exc_quad(T, A, W, 0, 1, lds);
+        }
         stage_done();
         d_exc(T, A, W, 0, 1, lds);
         stage_done();
@@ -2963,7 +3038,8 @@ void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& 
     // two launches, fixed grids; every wavefront pulls work until its device list runs out
     if (t.sym16) hipLaunchKernelGGL(k_exc_a<uint16_t>, dim3(EXA_MEDIUM16 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM16);
     else hipLaunchKernelGGL(k_exc_a<uint32_t>, dim3(EXA_MEDIUM32 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM32);
-    hipLaunchKernelGGL(k_exc_b, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
+    if (t.sym16 && t.rank_is_sym) hipLaunchKernelGGL(k_exc_b<true>, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
+    else hipLaunchKernelGGL(k_exc_b<false>, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3((unsigned)w.n_scan_blocks), dim3(SCAN_THREADS), 0, s, a, w);
