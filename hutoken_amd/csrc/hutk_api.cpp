@@ -114,8 +114,7 @@ struct hutk_ctx {
     DevBuf<int32_t> s_ids, s_status;
     // small batches: one page-locked host buffer, one device buffer each way
     DevBuf<uint8_t> s_small_in, s_small_out;
-    void* small_host = nullptr;      // page-locked staging of the small path ...
-    void* small_host_dev = nullptr;  // ... and its device address (null: staged through device buffers)
+    void* small_host = nullptr;
     // pipelined host path (hutk_encode_batch on large batches): two sets of chunk buffers, copy streams,
     // pinned staging for the rebased offsets and the small per-chunk results
     struct Pipe {
@@ -1309,41 +1308,24 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
         const size_t o_oo = 0, o_err = ((size_t)n_docs + 1) * 8, o_st = o_err + 8, o_ids = (o_st + (size_t)n_docs * 4 + 15) & ~(size_t)15;
         const size_t out_size = o_ids + (size_t)need * 4;
         if (!c->small_host) {
-            if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocMapped) != hipSuccess) c->small_host = nullptr;
-            const char* zc = getenv("HUTK_SMALL_ZERO_COPY");
-            if (c->small_host && !(zc && zc[0] == '0') &&
-                hipHostGetDevicePointer(&c->small_host_dev, c->small_host, 0) != hipSuccess)
-                c->small_host_dev = nullptr;
+            if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocDefault) != hipSuccess) c->small_host = nullptr;
         }
         if (c->small_host && in_size <= SMALL_HOST_BYTES && out_size <= SMALL_HOST_BYTES) {
+            HIP_TRY(c->s_small_in.reserve(in_size + 64));
+            HIP_TRY(c->s_small_out.reserve(out_size + 64));
             uint8_t* h = static_cast<uint8_t*>(c->small_host);
             memcpy(h + in_offs, offsets, ((size_t)n_docs + 1) * 8);
             memcpy(h + in_bytes, bytes, (size_t)n_bytes);
-            // A sentence is a few cache lines: the kernels read it from the page-locked buffer itself (its device address)
-            // and write ids, offsets, status and error word straight into its second half -- no copy call either way
-            // (HUTK_SMALL_ZERO_COPY=0: staged through device buffers with one copy up and one down, as in round 2).
-            uint8_t* hd = static_cast<uint8_t*>(c->small_host_dev);
-            const bool zero_copy = hd && in_size <= SMALL_HOST_BYTES / 2 && out_size <= SMALL_HOST_BYTES / 2;
-            uint8_t *di, *dout, *hout = h;
-            if (zero_copy) {
-                di = hd;
-                dout = hd + SMALL_HOST_BYTES / 2;
-                hout = h + SMALL_HOST_BYTES / 2;
-            } else {
-                HIP_TRY(c->s_small_in.reserve(in_size + 64));
-                HIP_TRY(c->s_small_out.reserve(out_size + 64));
-                HIP_TRY(hipMemcpyAsync(c->s_small_in.p, h, in_size, hipMemcpyHostToDevice, s));
-                di = c->s_small_in.p;
-                dout = c->s_small_out.p;
-            }
+            HIP_TRY(hipMemcpyAsync(c->s_small_in.p, h, in_size, hipMemcpyHostToDevice, s));
+            uint8_t* di = c->s_small_in.p;
+            uint8_t* dout = c->s_small_out.p;
             int rc = encode_device_impl(c, di + in_bytes, reinterpret_cast<const int64_t*>(di + in_offs), n_docs, n_bytes,
                                         reinterpret_cast<int32_t*>(dout + o_ids), need, reinterpret_cast<int64_t*>(dout + o_oo),
                                         reinterpret_cast<int32_t*>(dout + o_st), reinterpret_cast<int32_t*>(dout + o_err), s,
                                         nullptr, nullptr);
             if (rc) return rc;
-            if (!zero_copy) HIP_TRY(hipMemcpyAsync(h, dout, out_size, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h, dout, out_size, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
-            h = hout;
             int32_t err = 0;
             memcpy(&err, h + o_err, 4);
             if (err == HUTK_OK) {
