@@ -22,10 +22,10 @@ while time.time() < t_end:
     nm = rng.choice([40, 300, 1500, 4000, 9000])
     if is_byte:
         ents, sp = H.random_byte_vocab(seed, n_merges=nm, proper=rng.random() < 0.7, dup_ids=rng.random() < 0.2,
-                                       max_len=rng.choice([8, 12, 16, 24]))
+                                       max_len=rng.choice([8, 12, 16, 24, 31]))
         prefix = None
     else:
-        ents, sp = H.random_char_vocab(seed, n_merges=nm, drop_chars=rng.choice(["", "qz", "ő漢"]), max_len=rng.choice([8, 12, 16]))
+        ents, sp = H.random_char_vocab(seed, n_merges=nm, drop_chars=rng.choice(["", "qz", "ő漢"]), max_len=rng.choice([8, 12, 16, 24]))
         prefix = "▁"
     vp, spath = H.write_vocab(tmp, "s%d" % seed, ents, sp)
     mp = None
@@ -39,9 +39,25 @@ while time.time() < t_end:
         seed += 1
         continue
     docs = []
+    toks = []  # the vocabulary's keys as raw input (words of their own: the whole-word tables, up to 28 bytes)
+    if is_byte:
+        from hutoken_amd import vocab_files as vf
+        back = {c: b for b, c in vf.bytes_to_unicode().items()}
+        for k, _ in ents:
+            try:
+                t = bytes(back[c] for c in k.decode("utf-8")).strip(b" \n\t\0")
+            except (KeyError, UnicodeDecodeError):
+                continue
+            if t and b"\0" not in t:
+                toks.append(t)
+    else:
+        toks = [k.decode("utf-8").replace("\u2581", " ").strip().encode("utf-8") for k, _ in ents if not k.startswith(b"<0x")]
+        toks = [t for t in toks if t]
     for _ in range(rng.randint(200, 1500)):
         r = rng.random()
-        if r < 0.6:
+        if r < 0.15 and toks:
+            docs.append(b" ".join(rng.choice(toks) for _ in range(rng.randint(1, 30))))
+        elif r < 0.6:
             docs.append(H.random_text(rng, max_words=rng.choice([3, 12, 60])).encode("utf-8"))
         elif r < 0.8:
             w = bytes(rng.choice(b"etaoinshrdlu ") for _ in range(rng.randint(1, 400)))
