@@ -27,7 +27,8 @@ The JSON line also carries
                 contiguous shards (hutoken_amd.sharding.shard_by_bytes), rank r generating only its range
   end_to_end    (N = 1) the drop-in's host entry points on the same workload: page-locked host buffers in
                 and out through hutk_encode_batch (PCIe inclusive), and the Python list API on a sample
-  secondary     (N = 1) other configurations and off-distribution text, device-resident, 200k documents each
+  secondary     (N = 1) other configurations (config 5's single-GPU half and the merges path at 1 M documents) and
+                off-distribution text (200k documents each), device-resident
   cpu_baseline  (N = 1) the reference itself (oracle/_ref, compiled from the reference sources; kind
                 "reference") timed on the host cores on a bounded sample of the same workload: its list API
                 (`value`) and, marshalling-free, its C core through the internal encode() seam (`seam`).
@@ -159,16 +160,17 @@ def timed(batch, steps, warmup, sync):
 
 
 def secondary_runs(dev, dev_index, cores, no_verify):
-    """Other configurations, 200k documents each, device-resident, checked against the oracle."""
+    """Other configurations and off-distribution text, device-resident, checked against the oracle."""
     import torch
     from hutoken_amd import _capi, data as hdata, synth
     from oracle import oracle as O
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     out = []
     cases = [("C2 x VG (BASELINE config 2: ASCII)", "VG", False, lambda: synth.corpus("C2", 200_000)),
-             ("C5 x VL (config 5: Hungarian text, Llama-shaped vocab, prefix, non-byte mode)", "VL", False,
-              lambda: synth.corpus("C5", 200_000)),
-             ("C3 x VG + merges file (id-keyed merge path)", "VG", True, lambda: synth.corpus("C3", 200_000)),
+             ("C5 x VL (config 5's single-GPU half at its full size: 1 M documents of Hungarian text, Llama-shaped vocab, "
+              "prefix, non-byte mode)", "VL", False, lambda: synth.corpus("C5", 1_000_000)),
+             ("C5 x VL, 200 k documents", "VL", False, lambda: synth.corpus("C5", 200_000)),
+             ("C3 x VG + merges file (id-keyed merge path), 1 M documents", "VG", True, lambda: synth.corpus("C3", 1_000_000)),
              ("random words of 17-31 letters x VG (every word through the merge loop)", "VG", False,
               lambda: synth.random_words(17, 31, 200_000, 20)),
              ("random words of 33-62 letters x VG (every word through the exception kernels)", "VG", False,

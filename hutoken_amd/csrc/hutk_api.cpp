@@ -658,7 +658,12 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap,
                              int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err,
                              void* hip_stream) {
-    if (c && !c->host_only && !c->pattern.empty()) {
+    bool has_pattern = false;
+    if (c && !c->host_only) {  // (hutk_ctx_set_pattern writes the pattern under the same mutex)
+        std::lock_guard<std::recursive_mutex> lock(c->mu);
+        has_pattern = !c->pattern.empty();
+    }
+    if (has_pattern) {
         // The regex pre-token path splits with libc's regexec (core.c:350-378), which runs on the host: the bytes and offsets
         // come down once, the bitmaps of the matches go up, and the encode itself stays on the device buffers.  This form
         // of the call therefore SYNCHRONISES with the stream (the only one that does).
