@@ -27,13 +27,16 @@
 //                   start for every document that starts in the tile
 //              Words a lane cannot take (more than 32 units or 63 bytes, end outside the
 //              staged window, beyond the tile's prefix budget) become exception records.
-//   k_exc      one wavefront per exception word, work pulled from a device counter: the same
-//              merge rule by the whole wavefront; up to 1024 units in LDS (dense arrays), beyond
-//              that in HBM with dead-unit marks and per-chunk minima (bpe_wave_big).
-//   k_scan_*   exclusive scan of per-tile id counts (block sums, scan of sums, apply)
-//   k_gather   tile runs -> caller's ids array (symbol -> id); k_gather_exc for the tiles that
-//              also hold exception words
-//   k_doc_off  out_offsets[]
+//   k_exc_a    exception words of up to 63 bytes, one LANE per word (d_exc_lane_fast<1>: one dword per unit, rows read
+//              16 bytes at a time; d_exc_medium for vocabularies without the short form); the ends of the words whose
+//              end no tile saw (d_exc_ends)
+//   k_exc_b    words of up to 256 units: one lane per word again, 16 or 8 words per wavefront (d_exc_lane_fast<2>, <4>;
+//              d_exc_quad, sixteen lanes per word, for 32-bit symbols); longer ones: one wavefront per word (d_exc: up to
+//              1024 units in LDS, beyond that in HBM with dead-unit marks and per-chunk minima, bpe_wave_big)
+//   k_cut      the reference's over-long-word rule (a document ends in front of a word of more than 262144 bytes)
+//   k_scan     exclusive scan of per-tile id counts, one launch, decoupled look-back with tickets
+//   k_finish   tile runs -> caller's ids array (symbol -> id), also for the tiles that hold exception words; out_offsets[]
+//   k_tail_small  all of the above behind k_tiles for a batch of up to 32 tiles, in one launch
 //
 // Rank of a pair = vocabulary id of the concatenated bytes (src/core.c:700-722), or the rule's
 // line order on the id-keyed path (src/core.c:211-337).  On the device every possible token is a
