@@ -58,8 +58,8 @@ enum {
  * is_byte_encoder, ...) for the encode direction: src/lib.c:185-571
  * (initialize_context 128-183, vocab loader 243-388, special-character loader
  * 460-571) and struct EncodeContext (include/hutoken/taskqueue.h:16-25).
- * The decode tables, the AC automaton and the regex pattern are outside this
- * path.  `device` is a HIP device ordinal, or -1 for the current
+ * The decode tables are built alongside (hutk_decode_*), the regex pattern is set with
+ * hutk_ctx_set_pattern.  `device` is a HIP device ordinal, or -1 for the current
  * device.  On failure *out is NULL and hutk_last_error() holds the message. */
 int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_path,
                     const char* prefix, int is_byte_encoder, int device);
@@ -71,9 +71,9 @@ int hutk_ctx_create(hutk_ctx** out, const char* vocab_path, const char* special_
  * whose left, right and concatenation are vocabulary keys, result = the id of the
  * concatenation, a repeated (left id, right id) keeps its last rule.  A file with
  * no countable line (empty, comments only) leaves the string-keyed path in force,
- * as in the reference.  merges_path == NULL is hutk_ctx_create.
- * HUTK_E_UNSUPPORTED: a special-character replacement of more than one character
- * (several units per input item on this path). */
+ * as in the reference.  merges_path == NULL is hutk_ctx_create.  A special-character
+ * replacement of more than one character is several units per input item on this path
+ * (src/core.c:460-474 splits it per character): accepted, its words take the exception path. */
 int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* special_path,
                            const char* prefix, int is_byte_encoder, const char* merges_path,
                            int device);
@@ -85,7 +85,9 @@ int hutk_ctx_create_merges(hutk_ctx** out, const char* vocab_path, const char* s
  * the host by hutk_encode_batch / hutk_encode (one compiled pattern per host thread); pretokenizer and merge loop stay
  * on the GPU.  NULL returns to the hand-written splitter (src/parser.c).  HUTK_E_VALUE: the pattern does not compile
  * (the reference compares regcomp()'s result with `true` and goes on with an uncompiled pattern for every other error
- * code); HUTK_E_UNSUPPORTED: the context has a prefix.  hutk_encode_batch_device refuses a context with a pattern. */
+ * code).  A context with a prefix keeps it: the prefix goes with a document's first match (src/core.c:364-366, 421-451).
+ * hutk_encode_batch_device on a context with a pattern copies the bytes down for regexec and SYNCHRONISES with the
+ * stream (the only form of the call that does); the encode itself stays on the device buffers. */
 int hutk_ctx_set_pattern(hutk_ctx* ctx, const char* pattern);
 
 /* Several GPUs behind ONE context of one process (`device_mask`).  The reference's
@@ -135,7 +137,8 @@ int hutk_encode_batch(hutk_ctx* ctx, const uint8_t* bytes, const int64_t* offset
  * form bench.py times and a GPU data loader would call).  n_bytes must equal
  * offsets[n_docs] (the host needs it to size the launch without a sync).
  * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and
- * the call returns without synchronising; d_err receives the first device-side
+ * the call returns without synchronising (a context with a regex pattern excepted:
+ * hutk_ctx_set_pattern); d_err receives the first device-side
  * error code (HUTK_OK when none) and may be NULL.  d_bytes must be 16-byte
  * aligned.  A document with a word of more than 262144 bytes ends in front of that
  * word, as the reference's does (src/core.c:402-407, 503): d_status[i] =
