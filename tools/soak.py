@@ -14,6 +14,7 @@ O.build()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 t_end = time.time() + budget
+t_note = time.time() + 60
 tmp = tempfile.mkdtemp()
 n_vocab = n_docs = n_ids = 0
 while time.time() < t_end:
@@ -78,6 +79,9 @@ while time.time() < t_end:
         print(f"MISMATCH seed {seed} byte={is_byte} merges={mp is not None} rc={rc} first bad offset index {k}", flush=True)
         sys.exit(1)
     n_vocab += 1; n_docs += len(docs); n_ids += len(ids_o)
+    if time.time() > t_note:  # (a line a minute: a silent run is taken for a hung one)
+        print(f"... {n_vocab} vocabularies, {n_ids} ids, seed {seed}", flush=True)
+        t_note = time.time() + 60
     ctx.close(); orc.close()
     seed += 1
 print(f"soak OK: {n_vocab} vocabularies, {n_docs} documents, {n_ids} ids, seeds up to {seed - 1}")
