@@ -44,6 +44,8 @@
 // (left, right) -> merged is one 8-byte slot of a two-choice cuckoo table built by hutk_loader.cpp.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hutk_classify.h"
 #include "hutk_device.h"
 #include "hutk_lab.h"
@@ -1438,12 +1440,25 @@ struct HbmArr {  // L1-bypassing accesses: lanes of the wave exchange data throu
     }
 };
 
+// minimum over the wavefront, in every lane: DPP row shifts and broadcasts (the scan's pattern; a lane without a source
+// reads all ones), then lane 63's value.  (Twelve ds_bpermute round trips through the LDS pipe before: a merge of a long
+// exception word does four of these reductions.)
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-    for (int off = 32; off; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off, 64);
+    auto step = [&](auto ctrl, auto rows) {
+        const uint32_t oh = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+        const uint32_t ol = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, decltype(ctrl)::value, decltype(rows)::value, 0xf, false);
+        const uint64_t o = ((uint64_t)oh << 32) | ol;
         v = o < v ? o : v;
-    }
-    return v;
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    return ((uint64_t)h << 32) | l;
 }
 
 // Cooperative merge of n symbols held in Sa (pairs in Ma) by one wavefront.
@@ -1506,7 +1521,12 @@ constexpr int EXC_WIN = 16 + EXC_CHUNK + 16;      // staged bytes per step
 // over those.  A merge touches three pair results, so three chunks are rescanned.  The survivors are
 // compacted to the front at the end.  Sg/Mg are this word's regions of the exception arrays in HBM.
 constexpr uint32_t UNIT_DEAD = 0xFFFFFFFEu;
-__device__ int64_t bpe_wave_big(const DevTables& T, HbmArr Sg, HbmArr Mg, uint32_t* L1r, uint32_t* L1p, int64_t n,
+#ifndef HUTK_EXC_SHIFT_MAX
+#define HUTK_EXC_SHIFT_MAX 128
+#endif
+constexpr int64_t EXC_SHIFT_MAX = HUTK_EXC_SHIFT_MAX;  // longest word in LDS that d_exc merges by shifting (bpe_wave)
+template <class Arr>
+__device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1r, uint32_t* L1p, int64_t n,
                                 int lane) {
     const int64_t CH = (((n + EXC_LDS_UNITS - 1) / EXC_LDS_UNITS) + 63) & ~(int64_t)63;  // units per chunk
     const int NC = (int)((n + CH - 1) / CH);                                               // <= 1024
@@ -2500,7 +2520,13 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         }
         __syncthreads();
 
-        const int64_t left = in_lds ? bpe_wave(T, Sl_a, Ml_a, n, lane) : bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane);
+        // In LDS: short words by shifting the tail left after every merge (bpe_wave), longer ones by the same dead-unit
+        // marks and per-chunk best keys as the words in HBM (chunks of 64 units, at most 16 of them: a merge costs three
+        // chunk rescans instead of a shift of half the word, barriers and all)
+        __shared__ uint32_t s_l1[2 * (EXC_LDS_UNITS / 64)];
+        const int64_t left = !in_lds ? bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane)
+                           : n > EXC_SHIFT_MAX ? bpe_wave_big(T, Sl_a, Ml_a, s_l1, s_l1 + EXC_LDS_UNITS / 64, n, lane)
+                                               : bpe_wave(T, Sl_a, Ml_a, n, lane);
         const int na = alone ? T.n_prefix_alone : 0;
         int32_t* out = W.exc_tok + gbase;
         for (int i = lane; i < na; i += 64) out[i] = T.prefix_alone_ids[i];
