@@ -1358,8 +1358,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 const uint64_t slot = (uint64_t)exc_first + eidx;
                 if ((int64_t)slot < W.cap_exc) {
                     const uint64_t nxt = bits64(wmask32, ws + 1) & 0x7FFFFFFFFFFFFFFFull;
-                    const int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
-                    const bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                    int nb = nxt ? 1 + __builtin_ctzll(nxt) : 64;
+                    bool known_end = nxt != 0 && (ws + nb < NPOS || t0 + ws + nb >= A.n_bytes);
+                    if (nxt == 0) {
+                        // more than 63 bytes: the word may still end inside this tile's 1024 classified positions (a word
+                        // of a hundred letters mostly does): then its length is known here and d_exc_ends, which would
+                        // stage and classify the text again, has nothing to do for it
+                        int e = -1;
+                        for (int k = (ws + 64) >> 5; k < NPOS / 32 && e < 0; k++) {
+                            uint32_t m = wmask32[k];
+                            if (k == (ws + 64) >> 5) m &= ~0u << ((ws + 64) & 31);
+                            if (m) e = 32 * k + __builtin_ctz(m);
+                        }
+                        if (e >= 0) { nb = e - ws; known_end = true; }
+                    }
                     ExcRec rec;
                     rec.ws = t0 + ws;
                     rec.tok_base = 0;
@@ -1638,8 +1650,9 @@ constexpr int MEDIUM_UNITS = 64;
 constexpr int QUAD_UNITS = 256;  // longest word of k_exc_b's quad list (d_exc_quad, d_exc_lane_fast<4>)
 // A word of known length that d_exc_medium does not take (prefix units make it longer than MEDIUM_UNITS) goes straight on
 // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
-__device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane) {
-    const bool to_quad = leave && (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi;  // (prefix units + 63 bytes <= QUAD_UNITS; outside byte-encoder mode the list is d_exc_lane_fast<4>'s only)
+__device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane, int32_t len) {
+    // (a length from k_tiles can be anything up to a tile's window; outside byte-encoder mode the quad list is d_exc_lane_fast's only)
+    const bool to_quad = leave && (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && len + T.n_prefix <= QUAD_UNITS;
     const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
     if (bq | bw) {
         uint32_t aq = 0, aw = 0;
@@ -1887,7 +1900,7 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        if (NW == 1) medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
+        if (NW == 1) medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane, rec.len);
     }
 }
 
@@ -2074,7 +2087,7 @@ __device__ __forceinline__ void d_exc_medium(const DevTables& T, const BatchArgs
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane);
+        medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane, rec.len);
     }
 }
 
