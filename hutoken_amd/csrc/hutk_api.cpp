@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -118,11 +119,18 @@ struct hutk_ctx {
     // pipelined host path (hutk_encode_batch on large batches): two sets of chunk buffers, copy streams,
     // pinned staging for the rebased offsets and the small per-chunk results
     struct Pipe {
-        DevBuf<uint8_t> bytes[2];
-        DevBuf<int64_t> offs[2], offs_abs[2], oo[2], base;  // base: ids of the chunks already encoded
-        DevBuf<int32_t> ids[2], status[2], err[2];
+        // THREE sets of chunk buffers: the copy up of chunk c is enqueued while chunk c - 2's copy down is still under way
+        // (with two sets the host had to see that copy end first: a host round trip in the pipeline's critical path)
+        static constexpr int NB = 3;
+        DevBuf<uint8_t> bytes[NB];
+        DevBuf<int64_t> offs[NB], offs_abs[NB], oo[NB], base;  // base: ids of the chunks already encoded
+        DevBuf<int32_t> ids[NB], status[NB], err[NB];
         hipStream_t s_in = nullptr, s_out = nullptr;
-        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        hipEvent_t ev_in[NB] = {}, ev_comp[NB] = {}, ev_out[NB] = {};
+        // page-locked landing place of a chunk's error word and id total: a copy to PAGEABLE memory (a stack variable)
+        // waits for the copy engine's whole queue -- the next chunk's copy up included -- and the two directions then
+        // take turns instead of overlapping (tools/pipe_trace.py)
+        int64_t* h_small = nullptr;
         bool ready = false;
     } pipe;
 
@@ -385,7 +393,7 @@ void destroy(hutk_ctx* c) {
         c->s_bytes.release(); c->s_offsets.release(); c->s_out_offsets.release(); c->s_ids.release();
         c->s_status.release(); c->s_small_in.release(); c->s_small_out.release();
         if (c->small_host) (void)hipHostFree(c->small_host);
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < hutk_ctx::Pipe::NB; b++) {
             c->pipe.bytes[b].release(); c->pipe.offs[b].release(); c->pipe.oo[b].release(); c->pipe.offs_abs[b].release();
             c->pipe.ids[b].release(); c->pipe.status[b].release(); c->pipe.err[b].release();
             if (c->pipe.ev_in[b]) (void)hipEventDestroy(c->pipe.ev_in[b]);
@@ -393,6 +401,7 @@ void destroy(hutk_ctx* c) {
             if (c->pipe.ev_out[b]) (void)hipEventDestroy(c->pipe.ev_out[b]);
         }
         c->pipe.base.release();
+        if (c->pipe.h_small) (void)hipHostFree(c->pipe.h_small);
         if (c->pipe.s_in) (void)hipStreamDestroy(c->pipe.s_in);
         if (c->pipe.s_out) (void)hipStreamDestroy(c->pipe.s_out);
         for (auto& e : c->ev)
@@ -1152,11 +1161,12 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     if (!P.ready) {
         HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
+        for (int b = 0; b < hutk_ctx::Pipe::NB; b++) {
             HIP_TRY(hipEventCreateWithFlags(&P.ev_in[b], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&P.ev_comp[b], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&P.ev_out[b], hipEventDisableTiming));
         }
+        HIP_TRY(hipHostMalloc((void**)&P.h_small, 64, hipHostMallocDefault));
         P.ready = true;
     }
     // chunk boundaries (whole documents)
@@ -1174,7 +1184,8 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     first.push_back(n_docs);
     const int n_chunks = (int)first.size() - 1;
     const int64_t max_ids = hutk_ids_capacity(c, max_bytes, max_docs);
-    for (int b = 0; b < 2; b++) {
+    constexpr int NB = hutk_ctx::Pipe::NB;
+    for (int b = 0; b < NB; b++) {
         HIP_TRY(P.bytes[b].reserve((size_t)max_bytes + 64));
         HIP_TRY(P.offs[b].reserve((size_t)max_docs + 1));
         HIP_TRY(P.offs_abs[b].reserve((size_t)max_docs + 1));
@@ -1193,15 +1204,24 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
     HIP_TRY(hipMemsetAsync(P.base.p, 0, 8, sc));
     int64_t base = 0;  // ids of the chunks finalised so far
     int dev_err = 0;
+    const bool trace = getenv("HUTK_PIPE_TRACE") != nullptr;  // diagnostic: host-side time stamps per chunk on stderr
+    const auto t_start = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<double> tr;
     auto finalize = [&](int ch) -> int {  // chunk ch: results to the caller's arrays
-        const int b = ch & 1;
+        const int b = ch % NB;
         const int64_t d0 = first[ch], nd = first[ch + 1] - d0;
         HIP_TRY(hipStreamWaitEvent(P.s_out, P.ev_comp[b], 0));
-        int32_t err = 0;
-        HIP_TRY(hipMemcpyAsync(out_offsets + d0, P.oo[b].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, P.s_out));
-        HIP_TRY(hipMemcpyAsync(&err, P.err[b].p, 4, hipMemcpyDeviceToHost, P.s_out));
+        // first the two numbers the host needs (the chunk's error word and where its ids end), to page-locked memory;
+        // the out_offsets themselves follow with the ids
+        HIP_TRY(hipMemcpyAsync(P.h_small, P.err[b].p, 4, hipMemcpyDeviceToHost, P.s_out));
+        HIP_TRY(hipMemcpyAsync(P.h_small + 1, P.oo[b].p + nd, 8, hipMemcpyDeviceToHost, P.s_out));
+        if (trace) tr.push_back(now_ms());
         HIP_TRY(hipStreamSynchronize(P.s_out));
-        const int64_t total = out_offsets[d0 + nd] - base;  // the chunk's offsets are absolute already
+        if (trace) tr.push_back(now_ms());
+        const int32_t err = (int32_t)P.h_small[0];
+        const int64_t total = P.h_small[1] - base;  // the chunk's offsets are absolute already
+        HIP_TRY(hipMemcpyAsync(out_offsets + d0, P.oo[b].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, P.s_out));
         if (err && err != HUTK_E_WORD_TOO_LARGE && !dev_err) dev_err = err;  // (an over-long word is a note: k_cut has cut its document)
         if (base + total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
         if (total)
@@ -1213,10 +1233,12 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
         return HUTK_OK;
     };
     for (int ch = 0; ch < n_chunks; ch++) {
-        const int b = ch & 1;
+        const int b = ch % NB;
         const int64_t d0 = first[ch], nd = first[ch + 1] - d0;
         const int64_t b0 = offsets[d0], nb = offsets[d0 + nd] - b0;
-        if (ch >= 2) HIP_TRY(hipEventSynchronize(P.ev_out[b]));  // buffers b are free again
+        if (trace) tr.push_back(now_ms());
+        if (ch >= NB) HIP_TRY(hipEventSynchronize(P.ev_out[b]));  // buffers b are free again
+        if (trace) tr.push_back(now_ms());
         if (nb) HIP_TRY(hipMemcpyAsync(P.bytes[b].p, bytes + b0, (size_t)nb, hipMemcpyHostToDevice, P.s_in));
         HIP_TRY(hipMemcpyAsync(P.offs_abs[b].p, offsets + d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, P.s_in));
         HIP_TRY(hipEventRecord(P.ev_in[b], P.s_in));
@@ -1246,6 +1268,11 @@ static int encode_batch_pipelined(hutk_ctx* c, const uint8_t* bytes, const int64
         }
     }
     HIP_TRY(hipStreamSynchronize(P.s_out));
+    if (trace) {
+        fprintf(stderr, "pipe trace: %d chunks, end %.2f ms;", n_chunks, now_ms());
+        for (double v : tr) fprintf(stderr, " %.2f", v);
+        fprintf(stderr, "\n");
+    }
     out_offsets[n_docs] = base;
     switch (dev_err) {
         case HUTK_OK: return HUTK_OK;
