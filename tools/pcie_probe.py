@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""What the PCIe link gives: 512 MiB page-locked -> device, device -> page-locked, and both at once (torch copies on two
+streams): the floor of the host-buffer entry point."""
 import torch, time
 n = 512 << 20
 h = torch.empty(n, dtype=torch.uint8).pin_memory()

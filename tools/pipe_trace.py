@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Host-side time stamps of the chunked host path (HUTK_PIPE_TRACE=1 makes hutk_encode_batch print them on stderr): per
+chunk the loop start, the end of the wait for the chunk buffers, and the wait for the chunk's id total -- default
+chunking and 64 MB chunks one after the other."""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np
