@@ -249,6 +249,15 @@ def test_chunked_host_path_equals_the_simple_one(vg_files, monkeypatch):
                                         cap, poo.array.ctypes.data, pst.array.ctypes.data)
     assert rc == 0
     assert np.array_equal(poo.array, oo_s) and np.array_equal(pi.array[: int(oo_s[-1])], ids_s)
+    # many small chunks: the three sets of chunk buffers go round six times
+    monkeypatch.setenv("HUTK_PIPE_CHUNK_MB", "4")
+    pi.array[:] = -7
+    poo.array[:] = -7
+    rc = _capi.load().hutk_encode_batch(ctx.handle, pb.array.ctypes.data, po.array.ctypes.data, n, pi.array.ctypes.data,
+                                        cap, poo.array.ctypes.data, pst.array.ctypes.data)
+    monkeypatch.delenv("HUTK_PIPE_CHUNK_MB")
+    assert rc == 0
+    assert np.array_equal(poo.array, oo_s) and np.array_equal(pi.array[: int(oo_s[-1])], ids_s) and np.array_equal(pst.array, st_s)
     # an over-long word in the middle of a chunked batch
     docs_mid = int(n // 2)
     cut_at = int(o[docs_mid])
