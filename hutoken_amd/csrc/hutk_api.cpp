@@ -6,9 +6,14 @@
 #include <hip/hip_runtime.h>
 
 #include <regex.h>
+#if defined(__linux__)
+#include <sys/syscall.h>
+#include <unistd.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -1134,9 +1139,43 @@ int hutk_decode_batch(hutk_ctx* c, const int32_t* ids, const int64_t* id_offsets
     }
 }
 
+// NUMA node of the current HIP device (its PCI function's numa_node in sysfs), or -1
+static int device_numa_node() {
+    int dev = 0;
+    char bus[32] = {0};
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char* q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
+
+// Page-locked memory ON THE GPU'S NUMA NODE: on a two-socket host a buffer on the far node sends both copy directions
+// over the link between the sockets.  The calling thread's memory policy prefers the device's node while the pages are
+// allocated and pinned, and is put back afterwards (set_mempolicy(2); HUTK_HOST_ALLOC_NUMA=0: the policy is left alone).
 void* hutk_host_alloc(size_t n_bytes) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, n_bytes ? n_bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    bool bound = false;
+#if defined(__linux__) && defined(SYS_set_mempolicy)
+    const char* e = getenv("HUTK_HOST_ALLOC_NUMA");
+    const int node = (e && e[0] == '0') ? -1 : device_numa_node();
+    if (node >= 0 && node < 64) {
+        unsigned long mask = 1ul << node;
+        bound = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, &mask, 65ul) == 0;
+    }
+#endif
+    const hipError_t rc = hipHostMalloc(&p, n_bytes ? n_bytes : 1, hipHostMallocDefault);
+#if defined(__linux__) && defined(SYS_set_mempolicy)
+    if (bound) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+#endif
+    if (rc != hipSuccess) return nullptr;
     return p;
 }
 
