@@ -354,8 +354,10 @@ def main():
     n_corpus = args.docs or synth.KINDS[args.corpus][2]
     cores = os.cpu_count() or 1
     gen_threads = max(2, min(32, cores // max(world, 1)))
-    d_tot = torch.zeros(1, dtype=torch.int64, device=cdev)
-    gathered = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+    # two sets of buffers for the per-step all-gather: it is issued asynchronously and waited for one step later, so that
+    # the next step's kernels do not queue behind an 8-byte collective (the id totals are not an input of the encode)
+    d_tot = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(2)]
+    gathered = [[torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)] for _ in range(2)]
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -367,14 +369,25 @@ def main():
         t_gen = time.perf_counter() - t_gen
         batch = DeviceBatch(ctx, data, offs, dev)
 
+        pending = []  # handles of the all-gathers in flight (at most two)
+
         def step():
             batch.run()
             if dist_on:  # the path's one exchange: per-rank id totals
-                d_tot.copy_(batch.d_oo[n_docs:n_docs + 1])
-                dist.all_gather(gathered, d_tot)
+                k = len(pending) & 1
+                d_tot[k].copy_(batch.d_oo[n_docs:n_docs + 1])
+                pending.append(dist.all_gather(gathered[k], d_tot[k], async_op=True))
+                if len(pending) >= 2:
+                    pending[-2].wait()  # (its buffers are the next step's)
+
+        def drain():
+            if pending:
+                pending[-1].wait()
+            pending.clear()
 
         for _ in range(args.warmup):
             step()
+        drain()
         sync()
         batch.check_err()
         tile_ms = []
@@ -385,6 +398,7 @@ def main():
         for _ in range(args.steps):
             step()
             tile_ms.append(ctx.last_timing()[0])  # HIP events around k_tiles on the launch stream
+        drain()  # (every step's exchange is complete inside the timed region)
         sync()
         if dist_on:
             dist.barrier()
