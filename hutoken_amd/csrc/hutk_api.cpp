@@ -26,6 +26,9 @@
 
 #include "hutk_classify.h"
 #include "hutk_device.h"
+#ifndef HUTK_PTILES_DEFAULT
+#define HUTK_PTILES_DEFAULT 0
+#endif
 
 using namespace hutk;
 
@@ -728,6 +731,12 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
                               hip_stream, nullptr, nullptr);
 }
 
+// HUTK_PTILES=1/0: the persistent tile kernel (hutk_ptiles.hip) / k_tiles for the batches both can take
+static bool use_ptiles() {
+    const char* e = getenv("HUTK_PTILES");
+    return e ? atoi(e) != 0 : HUTK_PTILES_DEFAULT != 0;
+}
+
 static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
                               int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap, int64_t* d_out_offsets,
                               int32_t* d_status, int32_t* d_err, void* hip_stream, const uint32_t* d_word_bits,
@@ -784,7 +793,8 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     }
     launch_pre(A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
-    launch_tiles(c->dt, A, W, s);
+    if (use_ptiles() && ptiles_takes(c->dt, A)) launch_ptiles(c->dt, A, W, s);
+    else launch_tiles(c->dt, A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (small_tail(A)) {
         launch_tail_small(c->dt, A, W, s);

@@ -178,6 +178,10 @@ void launch_pre(const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_rebase_offsets(const int64_t* in, int64_t* out, int64_t n, hipStream_t s);
 void launch_add_base(int64_t* v, int64_t n, int64_t* base, hipStream_t s);  // v[i] += *base; *base = v[n-1]
 void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
+// hutk_ptiles.hip: the persistent form of the tile kernel (one workgroup per compute unit, no workgroup barrier; same
+// outputs).  ptiles_takes: is this vocabulary shape / batch one it handles?
+bool ptiles_takes(const DevTables& t, const BatchArgs& a);
+void launch_ptiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
 int64_t scan_blocks(int64_t n_tiles);
