@@ -32,6 +32,37 @@ def _stale(target, sources):
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
 
 
+class _BuildLock:
+    """One builder at a time per target (the ranks of a torchrun job import the package together), and a target that is
+    never seen half written: every compiler writes a temporary file that is renamed over the target."""
+
+    def __init__(self, target):
+        self.path = target + ".lock"
+        self.f = None
+
+    def __enter__(self):
+        import fcntl
+        os.makedirs(os.path.dirname(self.path), exist_ok=True)
+        self.f = open(self.path, "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def _compile(cmd, target):
+    tmp = "%s.tmp%d" % (target, os.getpid())
+    try:
+        subprocess.check_call([tmp if a == target else a for a in cmd])
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def _hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -42,9 +73,9 @@ def _hipcc():
 def build_synth(force=False):
     src = os.path.join(CSRC, "hutk_synth.c")
     if force or _stale(LIB_SYNTH, [src]):
-        os.makedirs(LIBDIR, exist_ok=True)
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall",
-                               "-o", LIB_SYNTH, src, "-lpthread"])
+        with _BuildLock(LIB_SYNTH):
+            if force or _stale(LIB_SYNTH, [src]):  # (another process may have built it while this one waited)
+                _compile(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-o", LIB_SYNTH, src, "-lpthread"], LIB_SYNTH)
     return LIB_SYNTH
 
 
@@ -52,11 +83,12 @@ def build_hip(force=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
     if force or _stale(LIB_HIP, deps):
-        os.makedirs(LIBDIR, exist_ok=True)
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-result", "-I" + INCLUDE, "-I" + CSRC,
-               *extra_flags, "-o", LIB_HIP, *srcs, "-lpthread"]
-        subprocess.check_call(cmd)
+        with _BuildLock(LIB_HIP):
+            if force or _stale(LIB_HIP, deps):
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                       "-Wall", "-Wno-unused-result", "-I" + INCLUDE, "-I" + CSRC,
+                       *extra_flags, "-o", LIB_HIP, *srcs, "-lpthread"]
+                _compile(cmd, LIB_HIP)
     return LIB_HIP
 
 
@@ -64,12 +96,14 @@ def build_pyshim(force=False):
     src = os.path.join(CSRC, "pyshim", "_hutoken_amd.c")
     if not os.path.exists(src):
         return None
-    if force or _stale(LIB_PYSHIM, [src, os.path.join(INCLUDE, "hutoken_amd.h")]):
-        os.makedirs(LIBDIR, exist_ok=True)
-        inc = sysconfig.get_paths()["include"]
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall",
-                               "-I" + inc, "-I" + INCLUDE, "-o", LIB_PYSHIM, src,
-                               "-L" + LIBDIR, "-lhutoken_amd", "-Wl,-rpath,$ORIGIN"])
+    deps = [src, os.path.join(INCLUDE, "hutoken_amd.h")]
+    if force or _stale(LIB_PYSHIM, deps):
+        with _BuildLock(LIB_PYSHIM):
+            if force or _stale(LIB_PYSHIM, deps):
+                inc = sysconfig.get_paths()["include"]
+                _compile(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall",
+                          "-I" + inc, "-I" + INCLUDE, "-o", LIB_PYSHIM, src,
+                          "-L" + LIBDIR, "-lhutoken_amd", "-Wl,-rpath,$ORIGIN"], LIB_PYSHIM)
     return LIB_PYSHIM
 
 

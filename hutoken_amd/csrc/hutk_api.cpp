@@ -1169,21 +1169,28 @@ static int device_numa_node() {
 
 // Page-locked memory ON THE GPU'S NUMA NODE: on a two-socket host a buffer on the far node sends both copy directions
 // over the link between the sockets.  The calling thread's memory policy prefers the device's node while the pages are
-// allocated and pinned, and is put back afterwards (set_mempolicy(2); HUTK_HOST_ALLOC_NUMA=0: the policy is left alone).
+// allocated and pinned -- only when the thread runs under the default policy: a process started under numactl --membind
+// or --interleave keeps what it was given -- and the default policy is what is put back afterwards
+// (get_mempolicy(2) / set_mempolicy(2); HUTK_HOST_ALLOC_NUMA=0: the policy is left alone).
 void* hutk_host_alloc(size_t n_bytes) {
     void* p = nullptr;
     bool bound = false;
-#if defined(__linux__) && defined(SYS_set_mempolicy)
+#if defined(__linux__) && defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
     const char* e = getenv("HUTK_HOST_ALLOC_NUMA");
     const int node = (e && e[0] == '0') ? -1 : device_numa_node();
     if (node >= 0 && node < 64) {
-        unsigned long mask = 1ul << node;
-        bound = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, &mask, 65ul) == 0;
+        int mode = -1;
+        unsigned long old_mask[16] = {0};
+        const bool known = syscall(SYS_get_mempolicy, &mode, old_mask, 16ul * 8 * sizeof(unsigned long), nullptr, 0ul) == 0;
+        if (known && mode == 0 /* MPOL_DEFAULT: nothing of the caller's to lose */) {
+            unsigned long mask = 1ul << node;
+            bound = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, &mask, 65ul) == 0;
+        }
     }
 #endif
     const hipError_t rc = hipHostMalloc(&p, n_bytes ? n_bytes : 1, hipHostMallocDefault);
-#if defined(__linux__) && defined(SYS_set_mempolicy)
-    if (bound) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+#if defined(__linux__) && defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+    if (bound) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT: what it was */, nullptr, 0ul);
 #endif
     if (rc != hipSuccess) return nullptr;
     return p;

@@ -459,4 +459,35 @@ HUTK_CLS_HD uint32_t classify16_dfa(const uint32_t (&d)[8], uint32_t dbits, cons
     return (acc >> 7) & 0xFFFFu;
 }
 
+// The same automaton as TWO walks side by side, for callers that are bound by the latency of the walk's chain of
+// dependent lookups rather than by instruction count (k_ptiles): the first covers window bytes 4..18 and yields the
+// starts of positions 0..7, the second starts cold at window byte 12 -- the same seven bytes of run-in in front of its
+// first used output as the first walk has -- covers bytes 12..26 and yields positions 8..15.  15 steps deep instead of 23.
+HUTK_CLS_HD uint32_t classify16_dfa2(const uint32_t (&d)[8], uint32_t dbits, const uint16_t* table, const uint8_t* lut,
+                                     bool* exotic) {
+    uint32_t col[23];
+    HUTK_CLS_UNROLL
+    for (int k = 4; k <= 26; k++) {
+        const uint32_t b = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        col[k - 4] = lut[b] + ((dbits >> k) & 1u) * (uint32_t)dfa::DOC_COL_BYTES;
+    }
+    uint32_t sa = ((d[0] >> 24) == 0x20u ? dfa::S_SM : dfa::S_WX) * dfa::ROW_BYTES;
+    uint32_t sb = ((d[2] >> 24) == 0x20u ? dfa::S_SM : dfa::S_WX) * dfa::ROW_BYTES;  // window byte 11
+    uint32_t acca = 0, accb = 0;  // bit i <-> window byte i + 1
+    const uint8_t* t8 = reinterpret_cast<const uint8_t*>(table);
+    HUTK_CLS_UNROLL
+    for (int i = 0; i < 15; i++) {
+        const int ka = 4 + i, kb = 12 + i;
+        const uint32_t ea = *reinterpret_cast<const uint16_t*>(t8 + (sa | col[ka - 4]));
+        const uint32_t eb = *reinterpret_cast<const uint16_t*>(t8 + (sb | col[kb - 4]));
+        acca |= (ea & 15u) << (ka - 4);
+        accb |= (eb & 15u) << (kb - 4);
+        sa = ea & 0xFF80u;
+        sb = eb & 0xFF80u;
+    }
+    *exotic = sa == (uint32_t)(dfa::S_EXOTIC * dfa::ROW_BYTES) || sb == (uint32_t)(dfa::S_EXOTIC * dfa::ROW_BYTES);
+    const uint32_t acc = (acca & 0x7FFFu) | (accb & ~0x7FFFu);
+    return (acc >> 7) & 0xFFFFu;
+}
+
 }  // namespace hutk

@@ -439,9 +439,85 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 cut_note_cold(W, (uint32_t)tile, mine, last_real16, &me.cutpos);
         }
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
+        uint32_t rest = own;  // my word starts that the general rounds below take
+        if constexpr (BYTE_MODE && !MULTI) {
+            if (!A.word_bits && HUTK_LAB_SLIM_ROUNDS) {  // (uniform)
+                // SHORT words first, in rounds that do nothing else.  The starts of my 16 positions by the length of their word,
+                // all sixteen at once: f32 = my starts and the next lane's; x: bit j = a start among positions j + 1 .. j +
+                // WORD_KEY, i.e. the word at j is at most WORD_KEY bytes (the key of the whole-word table) and ends inside the
+                // classified positions.  With a prefix the first word of a document is an exception word whatever its length
+                // (core.c:364-366, 421-451): left, like the long words, to the general rounds.
+                constexpr int WORD_KEY = sizeof(SymT) == 2 ? WORD_KEY_BYTES_16 : WORD_KEY_BYTES_32;
+                constexpr int KSH = sizeof(SymT) == 2 ? 16 : 32;  // bits of k[3] that are symbol, not key
+                const uint32_t f32 = flags | ((uint32_t)wmask16[lane + 1] << 16);
+                uint32_t x = f32 >> 1;
+                x |= x >> 1;
+                x |= x >> 2;
+                x |= x >> 4;
+                x |= x >> (WORD_KEY - 8);  // 1 .. 8 and WORD_KEY - 7 .. WORD_KEY
+                uint32_t shorts = own & x;
+                if (T.has_prefix) shorts &= ~(uint32_t)bits64(docm, 16 * lane + LOOKBACK);
+                rest = own & ~shorts;
+                uint32_t nS;
+                uint32_t sidx = wave_excl_scan(__popc(shorts), lane, &nS);
+                for (uint32_t r0 = 0; r0 < nS; r0 += 64) {
+                    while (shorts && sidx - r0 < 64u) {  // (each start is visited once, in the round it belongs to)
+                        stage[sidx - r0] = (uint16_t)(16 * lane + __builtin_ctz(shorts));
+                        shorts &= shorts - 1;
+                        sidx++;
+                    }
+                    wave_sync();
+                    if (r0 + lane < nS) {
+                        // One unaligned LDS read each for the start bits behind the word (at least 24 of them: the next start
+                        // is within WORD_KEY) and for its bytes; both table slots and the first byte's symbol loaded together.
+                        const uint32_t ws = stage[lane];
+                        uint32_t wb;
+                        __builtin_memcpy(&wb, reinterpret_cast<const uint8_t*>(wmask16) + ((ws + 1u) >> 3), 4);
+                        const uint32_t nb = 1u + (uint32_t)__builtin_ctz(wb >> ((ws + 1u) & 7u));
+                        uint4 key;
+                        __builtin_memcpy(&key, sb + LOOKBACK + ws, 16);
+                        const uint32_t isym = T.item_sym[key.x & 0xFFu];
+                        const uint64_t mlo = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+                        const uint64_t mhi = nb <= 8 ? 0ull : ((1ull << (8 * (nb - 8))) - 1ull);  // (nb <= 14)
+                        const uint32_t k0 = key.x & (uint32_t)mlo, k1 = key.y & (uint32_t)(mlo >> 32);
+                        const uint32_t k2 = key.z & (uint32_t)mhi, k3 = key.w & (uint32_t)(mhi >> 32);
+                        bool done = nb == 1;
+                        uint32_t sym = isym;
+                        if (T.word_mask) {  // (uniform)
+                            const uint32_t wh = word_hash(k0, k1, k2, k3);
+                            uint4 s1 = reinterpret_cast<const uint4*>(T.word_tab)[wh & T.word_mask];
+                            uint4 s2 = reinterpret_cast<const uint4*>(T.word_tab)[word_slot2(wh, T.word_mask)];
+                            // (both loads in flight together: short of registers, the compiler otherwise compares the first slot
+                            // before it asks for the second -- two memory round trips per round, seen in the ISA)
+                            asm volatile("" : "+v"(s1.x), "+v"(s2.x));
+                            // bitwise on purpose: with && the compiler fetches one word first and the rest only on a match
+                            // (a one-byte word matches no slot: keys have at least two bytes, an empty slot is all zero)
+                            const uint32_t d1 = KSH == 32 ? 0u : (s1.w ^ k3) << (KSH & 31);
+                            const uint32_t d2 = KSH == 32 ? 0u : (s2.w ^ k3) << (KSH & 31);
+                            const bool hit1 = ((s1.x ^ k0) | (s1.y ^ k1) | (s1.z ^ k2) | d1) == 0;
+                            const bool hit2 = ((s2.x ^ k0) | (s2.y ^ k1) | (s2.z ^ k2) | d2) == 0;
+                            if (nb != 1 && (hit1 || hit2)) {
+                                const uint32_t swd = hit1 ? s1.w : s2.w;
+                                sym = KSH == 32 ? swd : swd >> (KSH & 31);
+                                done = true;
+                            }
+                        }
+                        if (done) {
+                            S[ws] = Sym<SymT>::narrow(sym);
+                        } else if (HUTK_LAB_POOL_UNITS < WORD_KEY && nb > (uint32_t)HUTK_LAB_POOL_UNITS) {  // (measurement builds only)
+                            atomicOr(&excm[ws >> 5], 1u << (ws & 31));
+                            atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));
+                        } else {
+                            atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
+                        }
+                    }
+                    wave_sync();
+                }
+            }
+        }
         uint32_t nW;
-        const uint32_t wbase = wave_excl_scan(__popc(own), lane, &nW);  // index of this lane's first word
-        uint32_t rest = own, widx = wbase;  // my word starts not yet handed out, and the index of the first of them
+        const uint32_t wbase = wave_excl_scan(__popc(rest), lane, &nW);  // index of this lane's first word
+        uint32_t widx = wbase;  // the index of the first of my word starts not yet handed out
 #if HUTK_LAB_ALIGN
         asm volatile(".p2align " HUTK_STR(HUTK_LAB_ALIGN));
 #endif
@@ -607,7 +683,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                             i += L;
                         }
                     }
-                    if (n > LANE_MAX_UNITS) exc = true;
+                    if (n > HUTK_LAB_POOL_UNITS) exc = true;  // (LANE_MAX_UNITS; a lower limit sends the longest pooled words to the exception kernels: measured, hutk_lab.h)
                 }
                 if (gap) {
                     atomicAnd(&livem[ws >> 5], ~(1u << (ws & 31)));  // no ids

@@ -28,6 +28,12 @@
 #ifndef HUTK_LAB_ALIGN
 #define HUTK_LAB_ALIGN 0  // n: the round loop and the trip loop of k_tiles start on a 2^n-byte boundary (is a few per cent of difference between two builds code placement?)
 #endif
+#ifndef HUTK_LAB_SLIM_ROUNDS
+#define HUTK_LAB_SLIM_ROUNDS 0  // 1: words of up to 14 bytes in rounds of their own (unaligned LDS reads, no branches: 40 % fewer instructions in phase 5; measured: no faster, the merge phase is what a workgroup lives for -- profiles/r04_slim_rounds_ab.txt)
+#endif
+#ifndef HUTK_LAB_POOL_UNITS
+#define HUTK_LAB_POOL_UNITS 32  // = LANE_MAX_UNITS; lower: words of more units leave k_tiles' pool for the exception kernels (profiles/r04_pool_unit_sweep.txt)
+#endif
 #define HUTK_STR2(x) #x
 #define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD

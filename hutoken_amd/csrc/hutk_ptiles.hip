@@ -35,9 +35,16 @@ namespace hutk {
 #ifndef HUTK_PT_PROF
 #define HUTK_PT_PROF 0
 #endif
-#ifndef HUTK_PT_REFILL
-#define HUTK_PT_REFILL 32
+#ifndef HUTK_PT_PERTURB_VALU
+#define HUTK_PT_PERTURB_VALU 0
 #endif
+#ifndef HUTK_PT_PERTURB_SLEEP
+#define HUTK_PT_PERTURB_SLEEP 0
+#endif
+#ifndef HUTK_PT_REFILL
+#define HUTK_PT_REFILL 48
+#endif
+#define PT_MARK(name) asm volatile("; PTMARK " name)
 constexpr int PT_WAVES = HUTK_PT_WAVES;       // wavefronts of the one workgroup a compute unit holds
 #ifndef HUTK_PT_WGS
 #define HUTK_PT_WGS 1  // workgroups per compute unit (2: eight wavefronts per SIMD, 64 VGPRs, half the LDS each)
@@ -189,6 +196,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
     // (k_tiles phases 7 and 8; byte-encoder mode has neither arena words nor prefix-alone ids)
     // =====================================================================================================
     auto epilogue = [&](const int s) {
+        PT_MARK("epi_start");
         PtSlot& me = slots[s];
         const int64_t tile = (int64_t)me.tile;
         const int64_t t0 = tile * TILE_BYTES;
@@ -283,6 +291,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             before += (uint32_t)__popc(reinterpret_cast<const uint16_t*>(me.livem)[lr] & below);
             W.doc_tile_pos[d] = before;
         }
+        PT_MARK("epi_end");
         wave_sync();  // (every LDS read of the slot is issued before the slot is given back: the LDS serves them in order)
         if (lane == 0) {
             atomicOr(&ctl.free_slots, 1u << s);
@@ -306,7 +315,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         }
         return uni(ok) != 0;
     };
-    bool fe_room_ok = true;  // (out of front_end: the tile's words have their room in the queue)
     auto front_end = [&](const int s) -> uint32_t {
         PtSlot& me = slots[s];
         uint8_t* const sb = me.sb;
@@ -325,8 +333,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         const int64_t pre_o = pf_pre_o;  // offsets[dfirst + lane]
         const bool whole = pf_whole;
         // room in the queue for the tile's merge-loop words: asked for now, looked at when they are known
+        // The tile's count of unmerged words starts at ONE, taken away when the front end is over: a word that is merged while
+        // the front end still runs must not make the tile look finished.
         int room_old = 0;
-        if (lane == 0) room_old = atomicSub(&ctl.q_room, PT_ROOM_AHEAD);
+        if (lane == 0) {
+            room_old = atomicSub(&ctl.q_room, PT_ROOM_AHEAD);
+            atomicAdd(&me.pending, 1);
+        }
+        uint32_t pushed = 0;  // words of this tile put into the queue by the rounds themselves
         long long fe_t = HUTK_PT_PROF && prof_on ? clock64() : 0;
 #define PT_FE_STAMP(k)                              \
     do {                                            \
@@ -337,6 +351,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         }                                           \
     } while (0)
 
+        PT_MARK("fe_stage");
         // ---- 1. stage bytes -----------------------------------------------------------
         if (whole) {
             *reinterpret_cast<uint4*>(sb + 16 * lane) = pre0;
@@ -367,6 +382,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         }
         wave_sync();
 
+        PT_MARK("fe_docs");
         // ---- 2. document starts inside the window --------------------------------------
         for (int64_t d = dfirst + lane; d <= A.n_docs; d += 64) {
             const int64_t o = d == dfirst + lane ? pre_o : A.offsets[d];
@@ -380,6 +396,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         wave_sync();
 
         PT_FE_STAMP(11);
+        PT_MARK("fe_classify");
         // ---- 3. classification in registers: 32-byte window per lane ------------------
         // window-local index k <-> window index kb - 8 + k; own positions are k = 8..23
         const int kb = LOOKBACK + 16 * lane;
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
             bool exotic;
-            flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_dfa), s_dfa + dfa::TABLE_BYTES, &exotic);
+            flags = classify16_dfa2(dw, dbits, reinterpret_cast<const uint16_t*>(s_dfa), s_dfa + dfa::TABLE_BYTES, &exotic);  // (two walks side by side: a shorter chain)
             if (exotic) {  // overlong encodings: per-position decode
                 Win8 w8;
 #pragma unroll
@@ -444,7 +461,21 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         wmask16[lane] = (uint16_t)flags;
         wave_sync();
 
+#if HUTK_PT_PERTURB_VALU
+        {   // MEASUREMENT ONLY: extra VALU instructions (a dependent chain, every lane): is the kernel bound by VALU issue?
+            uint32_t x = flags | 1u;
+            for (int i = 0; i < HUTK_PT_PERTURB_VALU / 4; i++) {
+                x ^= x << 13; x ^= x >> 17;
+                asm volatile("" : "+v"(x));
+            }
+            if (x == 0x9E3779B9u) raise(A.err, HUTK_E_MEMORY);
+        }
+#endif
+#if HUTK_PT_PERTURB_SLEEP
+        for (int i = 0; i < HUTK_PT_PERTURB_SLEEP; i++) __builtin_amdgcn_s_sleep(127);  // MEASUREMENT ONLY: ~8 k idle cycles each
+#endif
         PT_FE_STAMP(12);
+        PT_MARK("fe_words");
         // ---- 4. words ------------------------------------------------------------------
         const int limit = (int)(tile_end - t0);  // words are starts at tile offsets < limit
         uint32_t own = flags;                    // starts that are words of this tile
@@ -497,6 +528,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         const uint32_t sl_base = wave_excl_scan((uint32_t)__popc(shorts) | ((uint32_t)__popc(longs) << 16), lane, &nSL);
         const uint32_t nS = nSL & 0xFFFFu, nL = nSL >> 16;
         PT_FE_STAMP(13);
+        PT_MARK("fe_short");
         {
             uint32_t widx = sl_base & 0xFFFFu, rest = shorts;
             for (uint32_t c0 = 0; c0 < nS; c0 += PT_STAGE) {
@@ -514,7 +546,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     wsv[r] = 0xFFFFFFFFu;
-                    kv[r] = s1v[r] = s2v[r] = make_uint4(0, 0, 0, 0);
                     if (64u * r + lane < c_end) {
                         const uint32_t ws = stage[64 * r + lane];
                         uint32_t wb;  // the start bits behind ws (at least 24 of them: the next start is within 14)
@@ -532,6 +563,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                         }
                     }
                 }
+                uint32_t missv = 0;  // bit r: my word of round r needs the merge loop
 #pragma unroll
                 for (int r = 0; r < NR; r++) {
                     if (wsv[r] != 0xFFFFFFFFu) {
@@ -543,13 +575,37 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                         const bool hit1 = ((s1.x ^ k.x) | (s1.y ^ k.y) | (s1.z ^ k.z) | ((s1.w ^ k.w) << 16)) == 0;
                         const bool hit2 = ((s2.x ^ k.x) | (s2.y ^ k.y) | (s2.z ^ k.z) | ((s2.w ^ k.w) << 16)) == 0;
                         if (hit1 || hit2) S[ws] = (SymT)((hit1 ? s1.w : s2.w) >> 16);
-                        else atomicOr(&mergem[ws >> 5], 1u << (ws & 31));  // needs the merge loop
+                        else missv |= 1u << r;
+                    }
+                }
+                // The words that need the merge loop go into the queue at once (one LDS atomic per chunk), into the room this
+                // front end asked for when it began; without that room they wait in mergem for the end of the front end.
+                if (__any(missv != 0)) {  // (uniform)
+                    uint32_t n_push;
+                    uint32_t off = wave_excl_scan((uint32_t)__popc(missv), lane, &n_push);
+                    const uint32_t have = (int)uni((uint32_t)room_old) >= PT_ROOM_AHEAD ? (uint32_t)PT_ROOM_AHEAD : 0u;
+                    if (pushed + n_push <= have) {
+                        uint32_t base = 0;
+                        if (lane == 0) {
+                            atomicAdd(&me.pending, (int)n_push);  // (before the entries can be seen: LDS order)
+                            base = atomicAdd(&ctl.q_tail, n_push);
+                        }
+                        off += uni(base);
+#pragma unroll
+                        for (int r = 0; r < NR; r++)
+                            if ((missv >> r) & 1u) s_ring[off++ & (uint32_t)(PT_QCAP - 1)] = PT_Q_VALID | ((uint32_t)s << 10) | wsv[r];
+                        pushed += n_push;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NR; r++)
+                            if ((missv >> r) & 1u) atomicOr(&mergem[wsv[r] >> 5], 1u << (wsv[r] & 31));
                     }
                 }
                 wave_sync();
             }
         }
         PT_FE_STAMP(14);
+        PT_MARK("fe_long");
         // 4c. Long words (rare in ordinary text): 15..28 bytes have the companion table (28 key bytes and the symbol in two
         // consecutive 16-byte slots behind the main table); up to 32 bytes a lane merges; the others, those whose end is
         // not among the classified positions, and -- with a prefix -- the first words of documents are exception words.
@@ -599,6 +655,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 wave_sync();
             }
         }
+        PT_MARK("fe_tail");
         {   // exception words of my tile (excm is final here): their records, and the tile's place on the list
             const uint32_t e16 = reinterpret_cast<const uint16_t*>(excm)[lane];
             if (__any(e16 != 0)) {  // (rare)
@@ -611,23 +668,22 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 }
             }
         }
-        uint32_t nm;
-        (void)wave_excl_scan((uint32_t)__popc(reinterpret_cast<const uint16_t*>(mergem)[lane]), lane, &nm);
         request_offsets();
-        // the room asked for at the start: enough?  (what is not needed goes back; a tile with more words asks again)
-        fe_room_ok = true;
+        // the room asked for at the start: what the rounds did not use goes back
+        if (lane == 0) {
+            const int have = room_old >= PT_ROOM_AHEAD ? PT_ROOM_AHEAD : 0;
+            const int back = have == 0 ? PT_ROOM_AHEAD : have - (int)pushed;  // (it was not there: undo)
+            if (back) atomicAdd(&ctl.q_room, back);
+        }
+        // the words the rounds left in mergem (long words, a tile with more words than the room asked for): the caller enqueues them
+        uint32_t nm = 0;
         {
-            const int have = (int)uni((uint32_t)room_old) >= PT_ROOM_AHEAD ? PT_ROOM_AHEAD : 0;
-            if (have == 0 && lane == 0) atomicAdd(&ctl.q_room, PT_ROOM_AHEAD);  // (it was not there: undo)
-            if ((int)nm <= have) {
-                if ((int)nm < have && lane == 0) atomicAdd(&ctl.q_room, have - (int)nm);
-            } else if (!reserve(nm - (uint32_t)have)) {
-                if (have && lane == 0) atomicAdd(&ctl.q_room, have);
-                fe_room_ok = false;
-            }
+            const uint32_t m16 = reinterpret_cast<const uint16_t*>(mergem)[lane];
+            if (__any(m16 != 0)) (void)wave_excl_scan((uint32_t)__popc(m16), lane, &nm);
         }
         wave_sync();
         PT_FE_STAMP(15);
+        PT_MARK("fe_end");
 #undef PT_FE_STAMP
         return nm;
     };
@@ -635,6 +691,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
     // the nm (> 0) words of my.mergem (tile in slot s) into the reserved entries.  The tile's count of unmerged words goes
     // up BEFORE the entries become visible (LDS order), so the word that brings it back to zero is the tile's last.
     auto enqueue = [&](const int s, const uint32_t nm) {
+        PT_MARK("enq");
         PtSlot& me = slots[s];
         uint32_t m16 = reinterpret_cast<const uint16_t*>(my.mergem)[lane];
         uint32_t tot;
@@ -650,6 +707,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             off++;
         }
         wave_sync();
+    };
+
+    // the front end of the tile in slot s is over and all its words are in the queue: its own count goes; true when no word
+    // is left unmerged (the tile's epilogue is this wavefront's, then)
+    auto fe_over = [&](const int s) -> bool {
+        uint32_t last = 0;
+        if (lane == 0) last = atomicSub(&slots[s].pending, 1) == 1 ? 1u : 0u;
+        return uni(last) != 0;
     };
 
     // =====================================================================================================
@@ -683,6 +748,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             return b;
         };
         for (;;) {
+            PT_MARK("mg_top");
             const bool active = holding && (best != NOKEY || again != 0);
             const unsigned long long am = __ballot(active);
             const int n_active = __popcll(am);
@@ -778,6 +844,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             // SECOND bucket (a filter bit of the first one says so; under 1 % of the lookups) is not followed up inside the
             // trip: the lane remembers which of its two lookups it was (`again`) and REPEATS both in the next trip, from the
             // buckets they need, beside the other lanes' ordinary ones.
+            PT_MARK("mg_trip");
             if (HUTK_PT_PROF) pc[7]++;
             if (holding && (best != NOKEY || again != 0)) {
                 uint32_t merged;
@@ -859,6 +926,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             idle = 0;
             continue;
         }
+        PT_MARK("loop_top");
         // the control words, all requested together: one LDS round trip per turn of the loop
         const uint32_t c_ready = ld(&ctl.ready), c_free = ld(&ctl.free_slots), c_tail = ld(&ctl.q_tail), c_head = ld(&ctl.q_head),
                        c_arena = ld(&ctl.arena_free), c_done = ld(&ctl.done_tiles);
@@ -868,6 +936,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         if (pend_slot >= 0) {
             if (reserve(pend_nm)) {
                 enqueue(pend_slot, pend_nm);
+                if (fe_over(pend_slot)) epi_slot = pend_slot;
                 pend_slot = -1;
                 idle = 0;
                 continue;
@@ -906,13 +975,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 uint32_t nm;
                 PT_ACC(1, nm = front_end(s));
                 if (HUTK_PT_PROF) pc[5]++;
-                if (nm == 0) {
-                    epi_slot = s;
-                } else if (fe_room_ok) {
-                    enqueue(s, nm);
-                } else {
+                if (nm != 0 && !reserve(nm)) {
                     pend_slot = s;
                     pend_nm = nm;
+                } else {
+                    if (nm != 0) enqueue(s, nm);
+                    if (fe_over(s)) epi_slot = s;
                 }
             }
             idle = 0;

@@ -153,8 +153,9 @@ int hutk_encode_batch_device(hutk_ctx* ctx, const uint8_t* d_bytes, const int64_
 /* Page-locked host memory for the buffers handed to hutk_encode_batch: with it the chunked
  * path of hutk_encode_batch copies by DMA while the previous chunk is being encoded and the one
  * before is being copied back (pageable buffers work too, at roughly a third of the rate).
- * The pages are taken from the current HIP device's NUMA node where the host has several (HUTK_HOST_ALLOC_NUMA=0: the
- * thread's memory policy is left alone).  The reference has no counterpart (it strdup()s every text, src/lib.c:770-772). */
+ * The pages are taken from the current HIP device's NUMA node where the host has several, provided the calling thread
+ * runs under the default memory policy (a policy given with numactl --membind / --interleave is the caller's and stays;
+ * HUTK_HOST_ALLOC_NUMA=0: the policy is never touched).  The reference has no counterpart (it strdup()s every text, src/lib.c:770-772). */
 void* hutk_host_alloc(size_t n_bytes);
 void hutk_host_free(void* p);
 

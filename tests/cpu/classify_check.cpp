@@ -47,6 +47,12 @@ static void starts_of(const std::vector<uint8_t>& text, const uint16_t* dfa_tabl
         uint32_t fs = hutk::classify16(d, dbits, &ex_s), fd = hutk::classify16_dfa(d, dbits, dfa_table, dfa_lut, &ex_d);
         if (ex_s) fs = fe;  // (what the kernel does with a window the fast forms hand back)
         if (ex_d) fd = fe;
+        {
+            bool ex_d2 = false;
+            uint32_t fd2 = hutk::classify16_dfa2(d, dbits, dfa_table, dfa_lut, &ex_d2);
+            if (ex_d2) fd2 = fe;
+            if (fd2 != fd) { fprintf(stderr, "two-walk automaton differs\n"); abort(); }
+        }
         for (int j = 0; j < 16 && p0 + j < n; j++) {
             if ((fe >> j) & 1u) out[0].push_back((uint32_t)(p0 + j));
             if ((fs >> j) & 1u) out[1].push_back((uint32_t)(p0 + j));
@@ -138,6 +144,17 @@ int main(int argc, char** argv) {
             bool exotic_d = false;
             const uint32_t fd = hutk::classify16_dfa(d, dbits, dfa_table, dfa_lut, &exotic_d);
             dfa_exotic += exotic_d;
+            bool exotic_d2 = false;  // the two-walk form (k_ptiles): the same answer wherever it does not hand the window back
+            const uint32_t fd2 = hutk::classify16_dfa2(d, dbits, dfa_table, dfa_lut, &exotic_d2);
+            if (!exotic_d2) {
+                uint32_t m = 0;
+                for (int j = 0; j < 16 && p0 + j < n; j++) m |= (uint32_t)expect[p0 + j] << j;
+                const uint32_t valid = (n - p0 >= 16) ? 0xFFFFu : ((1u << (n - p0)) - 1u);
+                if ((fd2 & valid) != m) {
+                    if (bad < 10) fprintf(stderr, "MISMATCH (two-walk automaton) case %ld pos %zu: want %04x got %04x\n", cs, p0, m, fd2 & valid);
+                    bad++;
+                }
+            }
             windows++;
             exotic_windows += exotic;
             for (int j = 0; j < 16 && p0 + j < n; j++) {
