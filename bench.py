@@ -18,11 +18,8 @@ with its own context; the only collective is an all-gather of the per-rank id to
 The JSON line also carries
   roofline      algorithmic HBM bytes of the dominant kernel (k_tiles) / its mean duration from HIP
                 events recorded around it on the launch stream in every timed step, against 8 TB/s;
-                `issue`: VALU wave-instructions per launch (committed PMC profile) x the MEASURED cost of a
-                wave-instruction (tools/valu_issue_bench.hip: 2 cycles for a few simple opcodes when two wavefronts
-                pair up, 4 for the rest; profiles/r03_issue_model.json prices the kernel's opcode mix) / (1024 SIMDs x
-                the launch's cycles): a range, from "every simple opcode pairs" to "none does" -- an upper estimate;
-                `latency`: what does bind the kernel (occupancy A/B, L2 latency counters: profiles/r03_latency.json)
+                `wavefront_cycles`: where a resident wavefront's cycles go (committed PMC profile; shares of one
+                counter's unit, none can pass 1); `latency`: what does bind the kernel (occupancy A/B, L2 latency counters)
   strong        (N > 1) BASELINE config 4: the SAME 1,000,000 documents cut into N byte-balanced
                 contiguous shards (hutoken_amd.sharding.shard_by_bytes), rank r generating only its range
   end_to_end    (N = 1) the drop-in's host entry points on the same workload: page-locked host buffers in
@@ -159,6 +156,38 @@ def timed(batch, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps, sum(tile_ms) / len(tile_ms)
 
 
+class _Env:
+    """Environment settings for the duration of a block (the library reads HUTK_NO_SEAM when a context is created and
+    HUTK_PTILES at every call)."""
+
+    def __init__(self, kv):
+        self.kv, self.old = kv or {}, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def c3_shard(n_shards, which=0):
+    """Shard `which` of BASELINE config 4's byte-balanced cut of the 1 M documents of C3 into n_shards (what ONE GPU of an
+    n_shards-GPU run encodes per step): generated from the lengths alone, as bench.py's strong mode does."""
+    import numpy as np
+    from hutoken_amd import sharding, synth
+    lens = synth.lengths("C3", 1_000_000)
+    offs_all = np.zeros(1_000_001, dtype=np.int64)
+    np.cumsum(lens, out=offs_all[1:])
+    first, count = sharding.shard_by_bytes(offs_all, n_shards)[which]
+    return synth.corpus("C3", int(count), first_doc=int(first))
+
+
 def secondary_runs(dev, dev_index, cores, no_verify):
     """Other configurations and off-distribution text, device-resident, checked against the oracle."""
     import torch
@@ -166,39 +195,89 @@ def secondary_runs(dev, dev_index, cores, no_verify):
     from oracle import oracle as O
     sync = lambda: torch.cuda.synchronize(dev)  # noqa: E731
     out = []
-    cases = [("C2 x VG (BASELINE config 2: ASCII)", "VG", False, lambda: synth.corpus("C2", 200_000)),
+    # (label, vocabulary, merges file?, generator, environment while the context is created, environment while it runs)
+    cases = [("C2 x VG (BASELINE config 2: ASCII)", "VG", False, lambda: synth.corpus("C2", 200_000), None, None),
+             ("C3 x VG, 1/8 byte-balanced shard of the 1 M documents (the per-GPU share of BASELINE config 4 at N = 8; "
+              "projected: no 8-GPU run)", "VG", False, lambda: c3_shard(8), None, None),
+             ("C3 x VG, 1/2 byte-balanced shard (config 4's per-GPU share at N = 2)", "VG", False, lambda: c3_shard(2), None, None),
              ("C5 x VL (config 5's single-GPU half at its full size: 1 M documents of Hungarian text, Llama-shaped vocab, "
-              "prefix, non-byte mode)", "VL", False, lambda: synth.corpus("C5", 1_000_000)),
-             ("C5 x VL, 200 k documents", "VL", False, lambda: synth.corpus("C5", 200_000)),
-             ("C3 x VG + merges file (id-keyed merge path), 1 M documents", "VG", True, lambda: synth.corpus("C3", 1_000_000)),
+              "prefix, non-byte mode)", "VL", False, lambda: synth.corpus("C5", 1_000_000), None, None),
+             ("C5 x VL, 200 k documents", "VL", False, lambda: synth.corpus("C5", 200_000), None, None),
+             ("C3 x VG + merges file (id-keyed merge path), 1 M documents", "VG", True, lambda: synth.corpus("C3", 1_000_000), None, None),
+             ("C3 x VG, 1 M documents, the persistent tile kernel (HUTK_PTILES=1: hutk_ptiles.hip; not the default)", "VG", False,
+              lambda: synth.corpus("C3", 1_000_000), None, {"HUTK_PTILES": "1"}),
              ("random words of 17-31 letters x VG (every word through the merge loop)", "VG", False,
-              lambda: synth.random_words(17, 31, 200_000, 20)),
+              lambda: synth.random_words(17, 31, 200_000, 20), None, None),
              ("random words of 33-62 letters x VG (every word through the exception kernels)", "VG", False,
-              lambda: synth.random_words(33, 62, 200_000, 10)),
+              lambda: synth.random_words(33, 62, 200_000, 10), None, None),
              ("random words of 70-120 letters x VG (exception kernels: one lane per word, up to 256 units)", "VG", False,
-              lambda: synth.random_words(70, 120, 100_000, 8)),
+              lambda: synth.random_words(70, 120, 100_000, 8), None, None),
              ("random words of 300-900 letters x VG (exception kernels: one wavefront per word)", "VG", False,
-              lambda: synth.random_words(300, 900, 20_000, 8)),
+              lambda: synth.random_words(300, 900, 20_000, 8), None, None),
              ("CJK paragraphs x VG (words of 300-1200 bytes under the reference's splitter; seams cut them)", "VG", False,
-              lambda: synth.cjk_paragraphs(60_000))]
+              lambda: synth.cjk_paragraphs(60_000), None, None),
+             ("CJK paragraphs x VG, the persistent tile kernel (HUTK_PTILES=1)", "VG", False,
+              lambda: synth.cjk_paragraphs(60_000), None, {"HUTK_PTILES": "1"}),
+             ("CJK paragraphs x VG WITHOUT the seam map (HUTK_NO_SEAM=1: every paragraph one word, as the reference sees it)", "VG",
+              False, lambda: synth.cjk_paragraphs(20_000), {"HUTK_NO_SEAM": "1"}, None),
+             ("ONE document of 100 MB x VG (the reference's own benchmark shape, scripts/benchmark.py:51-104), whole", "VG", False,
+              lambda: synth.big_document(100_000_000), None, None),
+             ("the same 100 MB document as 64 whitespace-aligned pieces (scripts/benchmark.py:26-48, threaded_benchmark.sh)", "VG",
+              False, lambda: (lambda d, o: (d, synth.whitespace_chunks(d, 64)))(*synth.big_document(100_000_000)), None, None),
+             ("ONE document of 1 GB x VG, whole (ids checked in tests/test_gpu_bigdoc.py, not here)", "VG", False,
+              lambda: synth.big_document(1_000_000_000), None, {"_no_verify": "1"}),
+             ("CJK text x VC (a vocabulary trained on CJK-dense text: merges across every frequent pair of neighbouring "
+              "characters saturate the seam map, nothing is cut; data/vc12257_*)", "VC", False, lambda: synth.cjk_text(20_000), None, None)]
     ctxs = {}
-    for label, vocab, merges, gen in cases:
-        key = (vocab, merges)
+    for label, vocab, merges, gen, env_ctx, env_run in cases:
+        key = (vocab, merges, tuple(sorted((env_ctx or {}).items())))
         vp, sp, kw = hdata.vocab_files(vocab)
         mp = hdata.merges_file(vocab) if merges else None
         if key not in ctxs:
-            ctxs[key] = (_capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=dev_index, merges_path=mp),
-                         O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp))
+            with _Env(env_ctx):
+                ctxs[key] = (_capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=dev_index, merges_path=mp),
+                             O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp))
         ctx, orc = ctxs[key]
         d, o = gen()
         b = DeviceBatch(ctx, d, o, dev)
-        sec, tile_ms = timed(b, 5, 2, sync)
-        ok = None if no_verify else b.verify(orc, d, o, cores)
+        skip_verify = bool(env_run and env_run.get("_no_verify"))
+        with _Env({k: v for k, v in (env_run or {}).items() if not k.startswith("_")}):
+            sec, tile_ms = timed(b, 5, 2, sync)
+        ok = None if (no_verify or skip_verify) else b.verify(orc, d, o, cores)
         out.append({"workload": label, "docs": b.n_docs, "bytes": b.n_bytes, "ids": b.n_ids(),
                     "value": round(b.n_bytes / sec / 1e9, 2), "unit": "GB/s", "ms_per_step": round(sec * 1e3, 4),
                     "k_tiles_ms": round(tile_ms, 4), "verified_vs_oracle": ok})
         del b
     return out
+
+
+def numa_info(arr, dev_index):
+    """NUMA node(s) of a page-locked buffer's pages (move_pages(2) with no target = query) and of the GPU's PCI function:
+    on a two-socket host a buffer on the far node halves the host path's rate; hutk_host_alloc asks
+    for the device's node (HUTK_HOST_ALLOC_NUMA=0: does not)."""
+    import ctypes
+    info = {"host_alloc_numa": os.environ.get("HUTK_HOST_ALLOC_NUMA", "default (prefer the device's node)")}
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(dev_index).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(dev_index), "pci_domain_id", 0)
+        devn = torch.cuda.get_device_properties(dev_index).pci_device_id
+        path = "/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node" % (dom, bus, devn)
+        info["device_node"] = int(open(path).read().strip())
+    except Exception as e:
+        info["device_node"] = None
+        info["device_node_error"] = str(e)[:80]
+    try:
+        npg = 64
+        step = max(4096, (arr.nbytes // npg) & ~4095)
+        pages = (ctypes.c_void_p * npg)(*[arr.ctypes.data + i * step for i in range(npg)])
+        status = (ctypes.c_int * npg)()
+        rc = ctypes.CDLL(None, use_errno=True).syscall(279, 0, npg, pages, None, status, 0)
+        info["buffer_nodes"] = sorted(set(int(x) for x in status)) if rc == 0 else None
+    except Exception as e:
+        info["buffer_nodes"] = None
+        info["buffer_nodes_error"] = str(e)[:80]
+    return info
 
 
 def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
@@ -233,7 +312,7 @@ def end_to_end(ctx, orc, data, offs, vp, sp, kw, dev_index, cores, no_verify):
         if not ok:
             raise SystemExit("PARITY FAILURE: hutk_encode_batch ids differ from the oracle")
     out = {"packed_pinned": {"value": round(n_bytes / best / 1e9, 2), "unit": "GB/s", "ms": round(best * 1e3, 2),
-                             "docs": n_docs, "verified_vs_oracle": ok,
+                             "docs": n_docs, "verified_vs_oracle": ok, "numa": numa_info(pb.array, dev_index),
                              "note": "hutk_encode_batch, page-locked host bytes+offsets in, host ids+offsets out "
                                      "(hutk_host_alloc); chunks of whole documents, H2D / kernels / D2H overlapped"}}
     # every GPU this process sees behind ONE context (hutk_ctx_add_device): only where there is more than one, and never
@@ -481,33 +560,20 @@ def main():
             "verified_vs_oracle": m["verified"],
             "gen_s": round(m["t_gen"], 2),
         }
-        # Instruction issue.  VALU wave-instructions of one launch (committed PMC profile of this workload) x the measured
-        # cost of one (profiles/r03_issue_model.json: the kernel's opcode mix priced with tools/valu_issue_bench.hip's
-        # per-opcode cycles), over the 1024 SIMDs, against the cycles this run's launch took at the profiled clock.
+        # Where a resident wavefront's cycles go (committed PMC profile of this workload).  Every share is a quotient of two
+        # SQ counters of the same unit (quad-cycles of one wavefront, summed over the wavefronts) and cannot exceed 1.  No
+        # "issue roofline": round 3's priced SQ_INSTS_VALU at an assumed 2..4 cycles and its upper end passed 1; round 4
+        # measured instead that 40 % fewer front-end instructions leave the kernel's time where it was
+        # (profiles/r04_slim_rounds_ab.txt): issue does not bind it.
         if iss:
-            valu = float(iss["valu_insts_per_launch"])
-            clk = float(iss["busy_cycles_per_launch"]) / (float(iss["kernel_ms_profiled"]) * 1e-3)  # cycles per second
-            cycles_now = clk * t_tile
-            model = {}
-            try:
-                model = json.load(open(os.path.join(ROOT, "profiles", "r03_issue_model.json")))
-            except Exception:
-                pass
-            c_lo = float(model.get("cycles_per_valu_inst_paired", 2.0))    # every simple opcode finds a partner wavefront
-            c_hi = float(model.get("cycles_per_valu_inst_unpaired", 4.0))  # none does
-            line["roofline"]["issue"] = {
-                "bound": "valu_issue", "valu_wave_insts": valu, "salu_wave_insts": iss.get("salu_insts_per_launch"),
+            line["roofline"]["wavefront_cycles"] = {
+                "valu_wave_insts": iss.get("valu_insts_per_launch"), "salu_wave_insts": iss.get("salu_insts_per_launch"),
+                "lds_wave_insts": iss.get("lds_insts_per_launch"),
+                "parked_at_waitcnt_or_barrier": iss.get("wait_any_frac"), "stalled_at_issue": iss.get("wait_inst_frac"),
+                "executing_valu": iss.get("valu_active_frac"),
                 "lds_bank_conflict_frac": iss.get("lds_bank_conflict_frac"), "ta_busy_frac": iss.get("ta_busy_frac"),
-                "cycles": round(cycles_now), "cycles_per_valu_inst": [c_lo, c_hi],
-                "frac": [round(valu * c_lo / (N_SIMD * cycles_now), 4), round(valu * c_hi / (N_SIMD * cycles_now), 4)],
-                "wait_frac_profiled": iss.get("wait_any_frac"),
-                "source": iss_src, "cost_model": "profiles/r03_issue_model.json",
-                "note": "share of the launch's SIMD cycles spent issuing VALU work, as a range: on gfx950 a wave64 VALU "
-                        "instruction costs 2 cycles for a few simple opcodes when two wavefronts pair up and 4 otherwise "
-                        "(measured on homogeneous streams, tools/valu_issue_bench.hip); low end = every simple opcode of the "
-                        "kernel's mix pairs, high end = none does.  An UPPER estimate, not the binding limit: with 7 instead of "
-                        "8 resident workgroups per CU the kernel loses 12 % (see `latency`), which a saturated issue port "
-                        "would not show"}
+                "unit": "shares of SQ_WAVE_CYCLES (per-wavefront quad-cycles, summed); the last two: of the LDS-active cycles / of the launch",
+                "source": iss_src}
         # What binds: the latency of chains of dependent table gathers (measured, profiles/r03_latency.json).
         try:
             lat = json.load(open(os.path.join(ROOT, "profiles", "r03_latency.json")))

@@ -2,6 +2,8 @@
 
   VG  GPT-2 shape, 50257 entries, is_byte_encoder=True, no prefix
   VL  SentencePiece/Llama shape, 32000 entries, is_byte_encoder=False, prefix U+2581
+  VC  GPT-2 shape, 12257 entries, trained on CJK-dense text (tools/make_vocab_cjk.py): merges across every frequent pair
+      of neighbouring characters, i.e. a saturated seam map; is_byte_encoder=True, no prefix
 """
 import gzip
 import hashlib
@@ -13,6 +15,8 @@ _DATA = os.path.join(_ROOT, "data")
 
 VOCABS = {
     "VG": dict(vocab="vg50257_vocab.txt", special="vg50257_special.txt", merges="vg50257_merges.txt",
+               kwargs=dict(prefix=None, is_byte_encoder=True)),
+    "VC": dict(vocab="vc12257_vocab.txt", special="vg50257_special.txt",
                kwargs=dict(prefix=None, is_byte_encoder=True)),
     "VL": dict(vocab="vl32000_vocab.txt", special="vl32000_special.txt",
                kwargs=dict(prefix="▁", is_byte_encoder=False)),

@@ -119,3 +119,89 @@ def cjk_paragraphs(n_docs, seed=0x434a4b50, lo=100, hi=400, alphabet=3000):
     offs = np.zeros(n_docs + 1, dtype=np.int64)
     np.cumsum(doc_bytes, out=offs[1:])
     return out, offs
+
+
+def cjk_text(n_docs, seed=0x434a4b54, lexicon=6000, alphabet=3000, lo=100, hi=400):
+    """CJK text WITH the structure BPE feeds on: paragraphs of lo..hi characters made of words of one to three characters
+    drawn (Zipf, s = 1.0) from a lexicon of `lexicon` words over `alphabet` code points from U+4E00 (the characters
+    themselves Zipf-distributed), written without spaces, a full stop or a comma behind one word in twelve; one to four
+    paragraphs per document with a line feed between.  Under the reference's splitter a paragraph is ONE word
+    (parser.c:102-138); a vocabulary trained on such text (data/vc12257_*, tools/make_vocab_cjk.py) has merges across every
+    frequent pair of neighbouring characters, so its seam map is saturated: nothing cuts the paragraphs.
+    -> (uint8 array, int64 offsets[n_docs+1]); numpy's PCG64 with fixed seeds, identical on every host."""
+    lex_rng = np.random.default_rng(0x434a4b4c)  # the lexicon is the same for every seed
+    pc = 1.0 / np.arange(1, alphabet + 1)
+    pc /= pc.sum()
+    wlen = lex_rng.choice([1, 2, 3], size=lexicon, p=[0.25, 0.55, 0.20])
+    wchars = lex_rng.choice(alphabet, size=int(wlen.sum()), p=pc).astype(np.uint32) + 0x4E00
+    wstart = np.concatenate(([0], np.cumsum(wlen)))
+    pw = 1.0 / np.arange(1, lexicon + 1)
+    pw /= pw.sum()
+    rng = np.random.default_rng(seed)
+    n_par = rng.integers(1, 5, n_docs)
+    plen = rng.integers(lo, hi + 1, int(n_par.sum()))  # characters per paragraph (the last word may overshoot by two)
+    out = []
+    offsets = np.zeros(n_docs + 1, dtype=np.int64)
+    par = 0
+    total = 0
+    # words for all paragraphs at once, cut where the running length reaches each paragraph's target
+    need = int(plen.sum())
+    words = rng.choice(lexicon, size=need, p=pw)  # (more than enough: every word has at least one character)
+    punct = rng.random(need)
+    wi = 0
+    for d in range(n_docs):
+        parts = []
+        for k in range(int(n_par[d])):
+            target = int(plen[par]); par += 1
+            got = 0
+            cps = []
+            while got < target:
+                w = int(words[wi])
+                cps.append(wchars[wstart[w]:wstart[w + 1]])
+                got += int(wlen[w])
+                if punct[wi] < 1.0 / 12.0:
+                    cps.append(np.array([0x3002 if punct[wi] < 1.0 / 30.0 else 0xFF0C], dtype=np.uint32))
+                    got += 1
+                wi += 1
+            cp = np.concatenate(cps)
+            b = np.empty((len(cp), 3), dtype=np.uint8)
+            b[:, 0] = 0xE0 | (cp >> 12)
+            b[:, 1] = 0x80 | ((cp >> 6) & 0x3F)
+            b[:, 2] = 0x80 | (cp & 0x3F)
+            parts.append(b.reshape(-1))
+            if k + 1 < int(n_par[d]):
+                parts.append(np.array([0x0A], dtype=np.uint8))
+        doc = np.concatenate(parts)
+        out.append(doc)
+        total += len(doc)
+        offsets[d + 1] = total
+    return np.concatenate(out), offsets
+
+
+def big_document(n_bytes, name="C3"):
+    """ONE document of at least n_bytes: the first documents of corpus `name` back to back (the reference's own benchmark
+    times one file of 1 MB .. 1 GB, scripts/benchmark.py:51-104).  -> (uint8 array, offsets [0, len])"""
+    lens = lengths(name, max(1, int(n_bytes // 100)))  # (documents are at least 16 bytes, ~250..500 on average: more than enough)
+    k = int(np.searchsorted(np.cumsum(lens), n_bytes)) + 1
+    d, o = corpus(name, min(k, len(lens)))
+    return d, np.array([0, len(d)], dtype=np.int64)
+
+
+def whitespace_chunks(data, n_chunks):
+    """Offsets that cut `data` into about n_chunks pieces at whitespace, as the reference's benchmark does before
+    batch_encode (scripts/benchmark.py:26-48: a cut moves right to the next ' ', '\n' or '\t', which begins the next
+    piece) -- with one more condition, so that the pieces' ids, concatenated, ARE the whole document's ids: the byte in front
+    of the cut is no whitespace (a cut inside a run of spaces changes which word the last space goes with)."""
+    n = len(data)
+    cuts = [0]
+    size = max(1, n // n_chunks)
+    ws = (data == 0x20) | (data == 0x0A) | (data == 0x09)
+    for k in range(1, n_chunks):
+        e = max(k * size, cuts[-1] + 1)
+        while e < n and not (ws[e] and not ws[e - 1]):
+            e += 1
+        if e >= n:
+            break
+        cuts.append(e)
+    cuts.append(n)
+    return np.array(cuts, dtype=np.int64)

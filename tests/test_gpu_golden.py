@@ -307,3 +307,20 @@ def test_g8_reference_fixtures(tmp_path):
     assert encode_texts(ctx, [c["text"] for c in cases]) == [c["ids"] for c in cases]
     for c in cases:
         assert ctx.encode_one(c["text"].encode("utf-8"))[0] == c["ids"]
+
+
+def test_g11_cjk_dense_vocabulary():
+    """VC: merges across neighbouring CJK characters, so the seam map cuts nothing and every paragraph is one word of
+    several hundred bytes (the exception kernels); VG on the same text (seams cut).  Expected ids: the compiled reference's."""
+    from hutoken_amd import data, synth
+    for g in load("g11_cjk_dense.json"):
+        vp, sp, kw = data.vocab_files(g["vocab"])
+        ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+        d, o = getattr(synth, g["generator"])(g["n_docs"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == g["corpus_sha256"]
+        ids, oo, st, rc = ctx.encode_packed(d, o)
+        assert rc == 0
+        res = [ids[oo[i]:oo[i + 1]].tolist() for i in range(g["n_docs"])]
+        assert res[:len(g["first"])] == g["first"]
+        assert int(oo[-1]) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]

@@ -139,3 +139,18 @@ def test_g6_decode(tmp_path, oracle_mod):
                 assert [ids, res] == g["first"][k]
             h.update(_json.dumps([ids, res], ensure_ascii=True).encode())
         assert h.hexdigest() == g["sha256"]
+
+
+def test_g11_cjk_dense_vocabulary(oracle_mod):
+    """A vocabulary with merges across neighbouring CJK characters (VC: no seam cuts a paragraph) and VG on the same text."""
+    from hutoken_amd import data, synth
+    for g in load("g11_cjk_dense.json"):
+        vp, sp, kw = data.vocab_files(g["vocab"])
+        orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+        d, o = getattr(synth, g["generator"])(g["n_docs"])
+        assert hashlib.sha256(d.tobytes()).hexdigest() == g["corpus_sha256"], "text generator drifted"
+        ids, oo, st = orc.encode_packed(d, o, 8)
+        res = [ids[oo[i]:oo[i + 1]].tolist() for i in range(g["n_docs"])]
+        assert res[:len(g["first"])] == g["first"]
+        assert int(oo[-1]) == g["n_ids"]
+        assert sha_ids(res) == g["sha256"]

@@ -100,31 +100,32 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
           "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
     json.dump(tj, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
     lines += [f"HBM-side traffic per k_tiles launch (corrected): {traffic / 1e9:.3f} GB", ""]
-# VALU issue.  What a wave64 VALU instruction costs a SIMD is measured (tools/valu_issue_bench.hip): 2 cycles for a few
-# simple opcodes when two wavefronts pair up, 4 otherwise; profiles/r03_issue_model.json prices the kernel's opcode mix
-# with it ("paired" = every simple opcode finds a partner, "unpaired" = none does).  GRBM_GUI_ACTIVE is summed over the 8 XCDs.
+# Where a resident wavefront's cycles go.  SQ_WAVE_CYCLES, SQ_WAIT_ANY, SQ_WAIT_INST_ANY and SQ_ACTIVE_INST_* all count
+# QUAD-cycles of one wavefront, summed over the wavefronts (MI355X_MICROARCH.md, PMC section: WAIT_ANY + WAIT_INST_ANY +
+# ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint), so their quotients are shares of a wavefront's residence and cannot exceed 1.
+# (Round 3 printed SQ_INSTS_VALU x an assumed 2..4 cycles over the SIMD cycles as an "issue roofline": a range whose upper
+# end passed 1; dropped.  SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU comes out at one quad-cycle per instruction: the counter
+# charges an instruction one quad-cycle whatever its opcode, so it does not price instructions either.)
 if "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
-    cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0
+    cycles = pmc["GRBM_GUI_ACTIVE"] / 8.0  # (summed over the 8 XCDs)
+    wc = pmc.get("SQ_WAVE_CYCLES")
+    share = lambda name: (pmc[name] / wc) if (wc and name in pmc) else None  # noqa: E731
     ij = {"tag": tag, "kernel": "k_tiles", "valu_insts_per_launch": pmc["SQ_INSTS_VALU"],
           "salu_insts_per_launch": pmc.get("SQ_INSTS_SALU"), "lds_insts_per_launch": pmc.get("SQ_INSTS_LDS"),
           "busy_cycles_per_launch": cycles, "kernel_ms_profiled": pmc_ms.get("GRBM_GUI_ACTIVE"),
-          "valu_issue_frac": pmc["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
-          "wait_any_frac": (pmc["SQ_WAIT_ANY"] / pmc["SQ_WAVE_CYCLES"]) if "SQ_WAIT_ANY" in pmc and pmc.get("SQ_WAVE_CYCLES") else None,
+          "unit_note": "SQ_* cycle counters are quad-cycles of one wavefront summed over wavefronts; shares are of SQ_WAVE_CYCLES",
+          "wait_any_frac": share("SQ_WAIT_ANY"), "wait_inst_frac": share("SQ_WAIT_INST_ANY"),
+          "valu_active_frac": share("SQ_ACTIVE_INST_VALU"),
           "lds_bank_conflict_frac": (pmc["SQ_LDS_BANK_CONFLICT"] / pmc["SQ_LDS_IDX_ACTIVE"])
           if "SQ_LDS_BANK_CONFLICT" in pmc and pmc.get("SQ_LDS_IDX_ACTIVE") else None,
           "ta_busy_frac": (pmc["TA_BUSY_avr"] / cycles) if "TA_BUSY_avr" in pmc else None,
           "workload_bytes": (j or {}).get("config", {}).get("bytes_per_gpu")}
     json.dump(ij, open(os.path.join(dst, f"{tag}_issue.json"), "w"), indent=1)
-    try:
-        model = json.load(open(os.path.join(dst, "r03_issue_model.json")))
-        c_lo, c_hi = model["cycles_per_valu_inst_paired"], model["cycles_per_valu_inst_unpaired"]
-    except Exception:
-        c_lo, c_hi = 2.0, 4.0
-    ij["valu_issue_frac_range"] = [pmc["SQ_INSTS_VALU"] * c_lo / (1024.0 * cycles), pmc["SQ_INSTS_VALU"] * c_hi / (1024.0 * cycles)]
-    json.dump(ij, open(os.path.join(dst, f"{tag}_issue.json"), "w"), indent=1)
-    lines += [f"VALU issue: {ij['valu_insts_per_launch']:.4g} wave-instructions x {c_lo:.2f} .. {c_hi:.2f} cycles (measured cost of the "
-              f"kernel's opcode mix, every simple opcode paired .. none) / (1024 SIMDs x {cycles:.4g} cycles) = "
-              f"{ij['valu_issue_frac_range'][0]:.3f} .. {ij['valu_issue_frac_range'][1]:.3f} of the launch's SIMD cycles", ""]
+    lines += [f"VALU wave-instructions per launch: {ij['valu_insts_per_launch']:.4g}; SALU {ij['salu_insts_per_launch'] or 0:.4g}; LDS {ij['lds_insts_per_launch'] or 0:.4g}", ""]
+    if ij["valu_active_frac"] is not None:
+        lines += [f"Share of a resident wavefront's cycles spent executing VALU instructions (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES): {ij['valu_active_frac']:.3f}", ""]
+    if ij["wait_inst_frac"] is not None:
+        lines += [f"... stalled at issue (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES): {ij['wait_inst_frac']:.3f}", ""]
     if ij["wait_any_frac"] is not None:
         lines += [f"Wavefronts parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES): {ij['wait_any_frac']:.3f}", ""]
     if ij["lds_bank_conflict_frac"] is not None:

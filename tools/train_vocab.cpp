@@ -3,6 +3,7 @@
 // infrastructure, not part of the product path).
 //
 //   train_vocab <kind 2|3|5> <seed> <n_docs> <n_merges> <out.txt> [bytes|chars] [pairs_out.txt]
+//   train_vocab 0 <text file> 0 <n_merges> <out.txt> [bytes|chars] [pairs_out.txt]     one document per line of the file
 //
 // "bytes" (default): initial symbols are the 256 byte values (GPT-2 shape).
 // "chars": ' ' is rewritten to U+2581 and initial symbols are whole UTF-8
@@ -61,7 +62,31 @@ int main(int argc, char** argv) {
 
     std::vector<int64_t> offs(n_docs + 1);
     uint8_t* bytes = nullptr;
-    int64_t total = hutk_synth_corpus(kind, seed, 0, n_docs, 8, &bytes, offs.data());
+    int64_t total = 0;
+    std::vector<uint8_t> file_bytes;
+    if (kind == 0) {  // a text file, one document per line (the line feeds are not part of the documents)
+        FILE* f = fopen(argv[2], "rb");
+        if (!f) return 1;
+        uint8_t buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) file_bytes.insert(file_bytes.end(), buf, buf + got);
+        fclose(f);
+        offs.assign(1, 0);
+        std::vector<uint8_t> packed;
+        for (size_t a = 0; a < file_bytes.size();) {
+            size_t b = a;
+            while (b < file_bytes.size() && file_bytes[b] != '\n') b++;
+            packed.insert(packed.end(), file_bytes.begin() + a, file_bytes.begin() + b);
+            offs.push_back((int64_t)packed.size());
+            a = b + 1;
+        }
+        file_bytes.swap(packed);
+        n_docs = (int64_t)offs.size() - 1;
+        bytes = file_bytes.data();
+        total = (int64_t)file_bytes.size();
+    } else {
+        total = hutk_synth_corpus(kind, seed, 0, n_docs, 8, &bytes, offs.data());
+    }
     if (total < 0) return 1;
     fprintf(stderr, "sample: %lld docs, %lld bytes\n", (long long)n_docs, (long long)total);
 
@@ -77,7 +102,7 @@ int main(int argc, char** argv) {
             wc[std::string((const char*)t + a, b - a)]++;
         }
     }
-    hutk_synth_free(bytes);
+    if (kind != 0) hutk_synth_free(bytes);
     std::vector<Word> words;
     words.reserve(wc.size());
     {
