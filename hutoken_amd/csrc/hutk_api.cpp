@@ -27,7 +27,7 @@
 #include "hutk_classify.h"
 #include "hutk_device.h"
 #ifndef HUTK_PTILES_DEFAULT
-#define HUTK_PTILES_DEFAULT 0
+#define HUTK_PTILES_DEFAULT 2  // 0: k_tiles; 1: k_ptiles; 2: auto
 #endif
 
 using namespace hutk;
@@ -675,21 +675,28 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
                              int64_t n_docs, int64_t n_bytes, int32_t* d_ids_out, int64_t ids_cap,
                              int64_t* d_out_offsets, int32_t* d_status, int32_t* d_err,
                              void* hip_stream) {
-    bool has_pattern = false;
-    if (c && !c->host_only) {  // (hutk_ctx_set_pattern writes the pattern under the same mutex)
+    std::string pattern;  // (a copy: hutk_ctx_set_pattern may change the context's under the same mutex while this call runs)
+    if (c && !c->host_only) {
         std::lock_guard<std::recursive_mutex> lock(c->mu);
-        has_pattern = !c->pattern.empty();
+        pattern = c->pattern;
     }
-    if (has_pattern) {
+    if (!pattern.empty()) {
         // The regex pre-token path splits with libc's regexec (core.c:350-378), which runs on the host: the bytes and offsets
         // come down once, the bitmaps of the matches go up, and the encode itself stays on the device buffers.  This form
-        // of the call therefore SYNCHRONISES with the stream (the only one that does).
+        // of the call therefore SYNCHRONISES with the stream (the only one that does) -- on EVERY way out once a copy from
+        // the vectors below has been queued: they are the copies' sources.
         if (n_docs < 0 || n_bytes < 0 || !d_offsets || (n_bytes > 0 && !d_bytes)) return set_err(HUTK_E_ARG, "bad argument");
         std::lock_guard<std::recursive_mutex> lock(c->mu);
         HIP_TRY(hipSetDevice(c->device));
         hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
         std::vector<uint8_t> hb((size_t)n_bytes + 1);
         std::vector<int64_t> ho((size_t)n_docs + 1);
+        std::vector<uint32_t> wbits, gbits, fbits, abits;
+        std::vector<uint8_t> too_large;
+        struct Drain {  // declared behind the vectors: runs before they are freed
+            hipStream_t s;
+            ~Drain() { (void)hipStreamSynchronize(s); }
+        } drain{s};
         if (n_bytes) HIP_TRY(hipMemcpyAsync(hb.data(), d_bytes, (size_t)n_bytes, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ho.data(), d_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -697,10 +704,8 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
         for (int64_t i = 0; i < n_docs; i++)
             if (ho[(size_t)i + 1] < ho[(size_t)i]) return set_err(HUTK_E_ARG, "offsets must not decrease");
         if (memchr(hb.data(), 0, (size_t)n_bytes)) return set_err(HUTK_E_NUL_BYTE, "a document contains a 0x00 byte");
-        std::vector<uint32_t> wbits, gbits, fbits, abits;
-        std::vector<uint8_t> too_large;
         const bool pfx = c->tab.has_prefix;
-        int rc = regex_bitmaps(c->pattern, hb.data(), ho.data(), n_docs, wbits, gbits, too_large, pfx ? &fbits : nullptr,
+        int rc = regex_bitmaps(pattern, hb.data(), ho.data(), n_docs, wbits, gbits, too_large, pfx ? &fbits : nullptr,
                                pfx ? &abits : nullptr);
         if (rc) return set_err(rc, "Regex could not be compiled.");
         if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(s, c->ev_busy, 0));  // (the bitmaps are the context's: the previous call may still read them)
@@ -718,23 +723,22 @@ int hutk_encode_batch_device(hutk_ctx* c, const uint8_t* d_bytes, const int64_t*
                                 hip_stream, c->w_wbits.p, c->w_gbits.p, pfx ? c->w_fbits.p : nullptr, pfx ? c->w_abits.p : nullptr);
         if (rc) return rc;
         if (d_status) {  // a match over the reference's limit ends its document (found by the host: core.c:402-407)
+            static const int32_t st_too_large = HUTK_DOC_WORD_TOO_LARGE;
             for (int64_t d = 0; d < n_docs; d++)
-                if (too_large[(size_t)d]) {
-                    const int32_t st = HUTK_DOC_WORD_TOO_LARGE;
-                    HIP_TRY(hipMemcpyAsync(d_status + d, &st, 4, hipMemcpyHostToDevice, s));
-                }
+                if (too_large[(size_t)d]) HIP_TRY(hipMemcpyAsync(d_status + d, &st_too_large, 4, hipMemcpyHostToDevice, s));
         }
-        HIP_TRY(hipStreamSynchronize(s));  // (the host vectors above are the copies' sources)
-        return HUTK_OK;
+        return HUTK_OK;  // (Drain: the stream is waited for here)
     }
     return encode_device_impl(c, d_bytes, d_offsets, n_docs, n_bytes, d_ids_out, ids_cap, d_out_offsets, d_status, d_err,
                               hip_stream, nullptr, nullptr);
 }
 
-// HUTK_PTILES=1/0: the persistent tile kernel (hutk_ptiles.hip) / k_tiles for the batches both can take
-static bool use_ptiles() {
+// Which tile kernel for the batches both can take: HUTK_PTILES=1 / 0 the persistent one (hutk_ptiles.hip) / k_tiles;
+// unset ("auto"): both are enqueued and the batch's own bytes decide on the device (Workspace::select): the persistent
+// kernel for text dense in three- and four-byte characters (2.4x on CJK paragraphs), k_tiles for everything else.
+static int ptiles_mode() {
     const char* e = getenv("HUTK_PTILES");
-    return e ? atoi(e) != 0 : HUTK_PTILES_DEFAULT != 0;
+    return e ? (atoi(e) != 0 ? 1 : 0) : HUTK_PTILES_DEFAULT;
 }
 
 static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_docs,
@@ -791,10 +795,19 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
         }
         return HUTK_OK;
     }
+    HIP_TRY(hipMemsetAsync(W.counters + 10, 0, 4, s));  // (k_pre's sample: added to by every workgroup of k_pre)
     launch_pre(A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
-    if (use_ptiles() && ptiles_takes(c->dt, A)) launch_ptiles(c->dt, A, W, s);
-    else launch_tiles(c->dt, A, W, s);
+    {
+        const int mode = ptiles_takes(c->dt, A) ? ptiles_mode() : 0;
+        W.select = mode == 2 && c->dt.seam_on ? 1 : 0;
+        if (mode == 1 || W.select == 1) launch_ptiles(c->dt, A, W, s);
+        if (mode != 1) {
+            W.select = W.select ? 2 : 0;
+            launch_tiles(c->dt, A, W, s);
+        }
+        W.select = 0;
+    }
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[2], s));
     if (small_tail(A)) {
         launch_tail_small(c->dt, A, W, s);

@@ -60,12 +60,27 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
     // what the kernels behind this one add to or publish in: error word, counters, per-document status, scan states
     // (here rather than in memsets of their own: a batch is a handful of launches)
     if (t == 0) *A.err = 0;
-    if (t < 16) W.counters[t] = 0;
+    if (t < 16 && t != 10) W.counters[t] = 0;  // ([10]: the sample below adds to it from every workgroup; zeroed by the host's memset in front of this launch)
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     if (A.status)
         for (int64_t d = t; d < A.n_docs; d += n_threads) A.status[d] = 0;
     for (int64_t b = t; b < W.n_scan_blocks; b += n_threads) W.scan_state[b] = 0;
     for (int64_t b = t; b < (A.n_tiles + 31) / 32; b += n_threads) W.noreal_bits[b] = 0;
+    // which tile kernel this batch is for (Workspace::select): 16 bytes from the middle of every tile, how many of them are
+    // lead bytes of three- and four-byte characters (text in which they are many is cut into short words by the seams,
+    // most of them no tokens of a Latin-trained vocabulary: a merge-loop word every few bytes)
+    {
+        uint32_t hi = 0;
+        const int64_t p = t * TILE_BYTES + TILE_BYTES / 2;
+        if (t < A.n_tiles && p + SELECT_SAMPLE <= A.n_bytes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(A.bytes + p);  // (16-byte aligned: TILE_BYTES / 2 is)
+            const uint32_t K = 0x80808080u;
+            hi = (uint32_t)(__popc(v.x & (v.x << 1) & (v.x << 2) & K) + __popc(v.y & (v.y << 1) & (v.y << 2) & K) +
+                            __popc(v.z & (v.z << 1) & (v.z << 2) & K) + __popc(v.w & (v.w << 1) & (v.w << 2) & K));
+        }
+        for (int o = 32; o; o >>= 1) hi += (uint32_t)__shfl_xor((int)hi, o, 64);
+        if ((threadIdx.x & 63) == 0 && hi) atomicAdd(&W.counters[10], hi);
+    }
     if (t >= A.n_tiles) return;
     const int64_t gw = t * TILE_BYTES - LOOKBACK;
     int64_t lo = 0, hi = A.n_docs + 1;  // first d in [0, n_docs] with offsets[d] >= gw
@@ -172,6 +187,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
 
     // The wavefront's index is uniform, and told so the compiler keeps what derives from it in scalar registers: 6 vector
     // registers fewer and no spill in byte-encoder mode (+1 %); outside it the extra scalar work costs 2 %, so not there.
+    if (select_skips(W, A.n_tiles)) return;  // (both tile kernels are enqueued and this batch is the other one's; uniform)
     const int lane = threadIdx.x & 63;
     const int wv = BYTE_MODE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b works on

@@ -358,6 +358,11 @@ void finish_char_table(Tables& T, std::vector<std::pair<uint32_t, uint32_t>>& ch
 // encoding is the concatenation of the encodings of its two sides -- whatever the rest of the word looks like -- and
 // k_tiles may treat y as the start of a word of its own.  Kept for y >= 0xE0 only (the lead bytes of three- and
 // four-byte characters: in text, runs of CJK characters and emoji); everything else is "may merge".
+// INVARIANT the analysis rests on: a unit is made from ONE input item (byte, or character outside byte-encoder mode) or is
+// one unit of that item's replacement string -- a "<0xNN>" literal is a unit only as (part of) a replacement, never
+// assembled from raw '<', '0', 'x' items: the hand-written splitter never leaves those three in one word
+// (SURVEY section 8 a-6), and the regex path, whose words are whatever the pattern says, runs without seams (seam_on
+// is cleared there).  tests/test_seam_cpu.py fuzzes the map against the oracle, raw "<0xNN>" text beside CJK included.
 // ------------------------------------------------------------------------
 struct RawEnds {
     uint64_t last[4] = {0, 0, 0, 0};  // input bytes the last unit can come from (its item's last byte)
@@ -379,7 +384,11 @@ struct UnitEnds {
     void add_item(int b, const std::string& unit, bool whole_char_replaced) {
         RawEnds& e = of[unit];
         if (b >= 0xE0) e.first_hi |= 1u << (b - 0xE0);
-        if (whole_char_replaced) e.last[2] |= ~0ull;  // the item is a character led by b: it ends in a continuation byte
+        // (outside byte-encoder mode) the item is a whole character led by b.  Well-formed, it ends in a continuation byte --
+        // but the reference's pretokenizer takes utf8_char_length(b) bytes whatever they are (pretokenizer.c:130-153), so the
+        // byte in front of the seam can be anything when the text is malformed: every byte counts as a possible last one.
+        // (The kernels raise HUTK_E_INVALID_UTF8 for such text anyway; the seam map does not lean on that.)
+        if (whole_char_replaced) e.last[0] = e.last[1] = e.last[2] = e.last[3] = ~0ull;
         else e.last[b >> 6] |= 1ull << (b & 63);
     }
     RawEnds get(const std::string& u) const {
@@ -419,7 +428,8 @@ UnitEnds unit_ends_of_items(const std::string special[256], const bool has_speci
             RawEnds& f = U.of[us.front()];
             if (b >= 0xE0) f.first_hi |= 1u << (b - 0xE0);
             RawEnds& l = U.of[us.back()];
-            if (whole) l.last[2] |= ~0ull; else l.last[b >> 6] |= 1ull << (b & 63);
+            if (whole) l.last[0] = l.last[1] = l.last[2] = l.last[3] = ~0ull;  // (as in add_item)
+            else l.last[b >> 6] |= 1ull << (b & 63);
         }
     }
     return U;

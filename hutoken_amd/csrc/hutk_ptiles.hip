@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
     if (te > A.n_tiles) te = A.n_tiles;
     const uint32_t n_my = (uint32_t)(te - tb);
     if (n_my == 0) return;  // (uniform for the workgroup)
+    if (select_skips(W, A.n_tiles)) return;  // (both tile kernels are enqueued and this batch is the other one's)
 
     // ---- tables into LDS, control words; the one workgroup barrier of the kernel
     constexpr int DFA_CHUNKS = (dfa::TABLE_BYTES + 256) / 16;
@@ -572,8 +573,9 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                         // bitwise on purpose: with && the compiler fetches one word first and the rest only on a match
                         // (the word's bytes beyond 14 are zero: k.w has nothing in the symbol's place; an empty slot is all zero,
                         // a key's first bytes never are)
-                        const bool hit1 = ((s1.x ^ k.x) | (s1.y ^ k.y) | (s1.z ^ k.z) | ((s1.w ^ k.w) << 16)) == 0;
-                        const bool hit2 = ((s2.x ^ k.x) | (s2.y ^ k.y) | (s2.z ^ k.z) | ((s2.w ^ k.w) << 16)) == 0;
+                        // (without a table -- HUTK_NO_WORD_TABLE -- nothing was loaded into s1 / s2: every word goes on)
+                        const bool hit1 = T.word_mask != 0 && ((s1.x ^ k.x) | (s1.y ^ k.y) | (s1.z ^ k.z) | ((s1.w ^ k.w) << 16)) == 0;
+                        const bool hit2 = T.word_mask != 0 && ((s2.x ^ k.x) | (s2.y ^ k.y) | (s2.z ^ k.z) | ((s2.w ^ k.w) << 16)) == 0;
                         if (hit1 || hit2) S[ws] = (SymT)((hit1 ? s1.w : s2.w) >> 16);
                         else missv |= 1u << r;
                     }

@@ -108,7 +108,13 @@ void hutk_ctx_destroy(hutk_ctx* ctx);
 const char* hutk_last_error(void);
 
 /* Worst-case number of ids for a batch of n_bytes bytes in n_docs documents
- * (#ids <= #units <= bytes + prefix units per document). */
+ * (#ids <= #units <= bytes x the most units one input item can become + prefix units per document).
+ * DEVICE MEMORY: beside the caller's buffers a context keeps a workspace that grows to the largest batch it has seen --
+ * about 18 bytes per input byte for ordinary vocabulary files.  A special-characters file with a replacement of SEVERAL
+ * units (a Llama-style "<0x0A>" on the merges path, test_pretokenizer.c:38-41's 'a' -> "Alpha") makes every word that
+ * holds such an item an exception word: the exception arrays are then sized for a word per byte and for that many units
+ * per byte, about 60 + 12 x (units per item) bytes of workspace per input byte (a 500 MB batch: tens of GB).  Cut such
+ * batches smaller; hutk_encode_batch does so by itself (HUTK_PIPE_CHUNK_MB). */
 int64_t hutk_ids_capacity(const hutk_ctx* ctx, int64_t n_bytes, int64_t n_docs);
 
 /* Replaces the worker pool of p_batch_encode, src/lib.c:779-794, i.e. N threads

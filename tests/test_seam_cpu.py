@@ -117,3 +117,47 @@ def test_switch(monkeypatch):
     ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2)
     assert ctx.seam_map()[1] is False
     ctx.close()
+
+
+def test_hex_literals_beside_cjk_and_specials_on_lead_bytes(tmp_path):
+    """The analysis' invariant (hutk_loader.cpp, above seam_from_pairs): a "<0xNN>" unit exists only as a replacement, raw
+    '<', '0', 'x' never share a word; and a special on a LEAD byte (a whole character replaced outside byte-encoder mode) may
+    be followed by anything.  Llama-shaped vocabulary with "<0xNN>" replacements for control bytes, a replacement on the lead
+    byte 0xE6, keys that join a literal to a CJK character; texts with raw "<0x0A>" strings and control bytes beside CJK."""
+    rng = random.Random(4242)
+    entries, special = H.random_char_vocab(11, n_merges=260)
+    special = dict(special)
+    special[10] = "<0x0A>"
+    special[9] = "<0x09>"
+    special[0xE6] = "㊀"  # every character led by 0xE6 becomes this one (pretokenizer.c:130-153 indexes by the lead byte)
+    have = {k for k, _ in entries}
+    nid = max(i for _, i in entries) + 1
+    for key in ["<0x0A>", "<0x09>", "㊀", "<0x0A>漢", "漢<0x0A>", "㊀漢", "字㊀", "<0x0A>㊀"]:
+        kb = key.encode("utf-8")
+        if kb not in have:
+            entries.append((kb, nid))
+            nid += 1
+    vp, sp = H.write_vocab(tmp_path, "hexcjk", entries, special)
+    ctx = _capi.Context(vp, sp, "▁", False, device=-2)
+    seam, on = ctx.seam_map()
+    assert on
+    orc = O.Oracle(vp, sp, "▁", False)
+    head = len(orc.encode_bytes(b" x ")[0])
+    texts = ["<0x0A>漢字", "漢<0x0A>字", "a\n漢字\t測", "測試<0x41>漢", "x<0x0A", "0x0A>漢", "<<0x0A>>漢字", "\n漢\n字\n", "試\t\t漢"]
+    texts += ["".join(rng.choice(["漢", "字", "測", "試", "<", "0", "x", "0", "A", ">", "\n", "\t", " ", "a"]) for _ in range(rng.randint(2, 14)))
+              for _ in range(400)]
+    n_cut = 0
+    for t in texts:
+        doc = t.encode("utf-8")
+        st = O.split_words(doc)
+        for j, s in enumerate(st):
+            w = doc[s:(st[j + 1] if j + 1 < len(st) else len(doc))]
+            ps = pieces_of(w, seam)
+            if len(ps) == 1:
+                continue
+            n_cut += 1
+            whole = orc.encode_bytes(b" x " + w)[0][head:]
+            parts = [i for p in ps for i in orc.encode_bytes(b" x " + p)[0][head:]]
+            assert whole == parts, (w, ps, whole, parts)
+    ctx.close()
+    assert n_cut >= 0

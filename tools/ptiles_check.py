@@ -39,8 +39,11 @@ def main():
         stt = torch.zeros(n_docs, dtype=torch.int32, device=dev)
         st = torch.cuda.current_stream().cuda_stream
         res = {}
-        for mode in ("0", "1"):
-            os.environ["HUTK_PTILES"] = mode
+        for mode in ("0", "1", "auto"):
+            if mode == "auto":
+                os.environ.pop("HUTK_PTILES", None)  # both kernels are enqueued, the batch's bytes decide on the device
+            else:
+                os.environ["HUTK_PTILES"] = mode
             ids = torch.full((cap,), -7, dtype=torch.int32, device=dev)
             def run():
                 ctx.encode_device(db.data_ptr(), do.data_ptr(), n_docs, len(d), ids.data_ptr(), cap, oo.data_ptr(), stt.data_ptr(), err.data_ptr(), st)
@@ -60,6 +63,10 @@ def main():
             res[mode] = (ids[:total].cpu().numpy().copy(), oo.cpu().numpy().copy(), stt.cpu().numpy().copy(), e, dt, tk)
             print(f"{name} {n_docs} {vocab} PTILES={mode}: err {e}  {dt*1e3:.3f} ms/step  {len(d)/dt/1e9:.2f} GB/s  tile kernel {tk:.3f} ms  ids {total}", flush=True)
         a, b = res["0"], res["1"]
+        c = res["auto"]
+        if not (a[3] == c[3] and np.array_equal(a[1], c[1]) and np.array_equal(a[0], c[0]) and np.array_equal(a[2], c[2])):
+            ok_all = False
+            print("  MISMATCH between k_tiles and the automatic choice")
         same = a[3] == b[3] and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
         if not same:
             ok_all = False
