@@ -339,7 +339,10 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + n_tiles / 32 + 16));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
-    HIP_TRY(c->w_counters.reserve(16));
+    if (!c->w_counters.p) {  // (zeroed once: counters[10], k_pre's sample, is zeroed for the NEXT call by k_scan / k_tail_small)
+        HIP_TRY(c->w_counters.reserve(16));
+        HIP_TRY(hipMemset(c->w_counters.p, 0, 16 * sizeof(uint32_t)));
+    }
     HIP_TRY(c->w_err.reserve(1));
     // exception words: longer than a lane takes (more than LANE_MAX_UNITS bytes), first of their document, or cut off by
     // a tile's budget -- unless items of several units make ANY word one (then: at most a word per byte)
@@ -795,7 +798,6 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
         }
         return HUTK_OK;
     }
-    HIP_TRY(hipMemsetAsync(W.counters + 10, 0, 4, s));  // (k_pre's sample: added to by every workgroup of k_pre)
     launch_pre(A, W, s);
     if (c->timing) HIP_TRY(hipEventRecord(c->ev[1], s));
     {

@@ -121,15 +121,16 @@ struct Workspace {
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)
     long long* prof;           // diagnostic: [n_tiles][10] clock64 stamps of k_tiles, or null
     // Which tile kernel encodes the batch when BOTH are enqueued (hutk_api.cpp, "auto"): k_pre samples the batch's bytes
-    // (counters[10] = bytes >= 0xE0 among the SELECT_SAMPLE bytes it looks at per tile); a batch in which they are at
+    // (counters[10] = bytes >= 0xE0 among the SELECT_SAMPLE bytes it looks at in one tile of SELECT_BLOCK_STRIDE); a batch in which they are at
     // least one byte in SELECT_DENSE_DIV is "dense".  select: 0 = run; 1 = run only for a dense batch (k_ptiles); 2 = run
     // only for one that is not (k_tiles).  The kernel that is not chosen returns at once.
     int32_t select;
 };
-constexpr int SELECT_SAMPLE = 16, SELECT_DENSE_DIV = 8;
+constexpr int SELECT_SAMPLE = 16, SELECT_DENSE_DIV = 8, SELECT_BLOCK_STRIDE = 8;  // (k_pre: 256 tiles per workgroup)
 __device__ __forceinline__ bool select_skips(const Workspace& W, int64_t n_tiles) {
     if (W.select == 0) return false;
-    const bool dense = (int64_t)W.counters[10] * SELECT_DENSE_DIV >= n_tiles * SELECT_SAMPLE;
+    // (about one tile in SELECT_BLOCK_STRIDE is sampled; the batches both kernels take have thousands of tiles)
+    const bool dense = (int64_t)W.counters[10] * SELECT_DENSE_DIV * SELECT_BLOCK_STRIDE >= n_tiles * SELECT_SAMPLE;
     return (W.select == 1) != dense;
 }
 

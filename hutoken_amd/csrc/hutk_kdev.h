@@ -62,27 +62,6 @@ __device__ __forceinline__ int32_t sym_to_id(const DevTables& T, uint32_t s) {
     return s < T.n_sym ? T.sym_id[s] : -1;
 }
 
-// k_cut's notes from a tile (rare, out of line so that the hot path does not carry them): no word start of the
-// reference's own among the tile's positions -> its bit in noreal_bits; starts, but none in the halo -> this may be the
-// tile in front of a run, and its last start is where k_cut would cut: 1 + position into *cutpos (LDS; the ids in front
-// of it are counted in the epilogue).
-static __device__ __noinline__ void cut_note_cold(Workspace W, uint32_t tile, unsigned long long mine, uint32_t last16, uint32_t* cutpos) {
-    if ((threadIdx.x & 63) != 0) return;
-    if (mine == 0) {
-        atomicOr(&W.noreal_bits[tile >> 5], 1u << (tile & 31));
-        atomicAdd(&W.counters[6], 1u);
-    } else {  // last16: the starts (without seams) of the tile's last lane that has one
-        *cutpos = 1u + (uint32_t)(16 * (63 - __builtin_clzll(mine)) + 31 - __builtin_clz(last16 & 0xFFFFu));
-    }
-}
-
-// Out of line on purpose: the per-position form indexes its window dynamically (scratch), and inlined that
-// would put a scratch store of the window on the hot path of every tile.
-struct Win8 { uint32_t d[8]; };  // by value: the window travels in registers
-static __device__ __noinline__ uint32_t classify16_exact_cold(Win8 w, uint32_t dbits) {
-    return classify16_exact(w.d, dbits);
-}
-
 // One wavefront per workgroup: LDS instructions of a wavefront execute in order, so lanes exchange data
 // through LDS without s_barrier -- and without the "wait for every outstanding global load and STORE"
 // that __syncthreads() implies.  This only stops the compiler from moving LDS accesses across the point.

@@ -51,6 +51,33 @@
 
 namespace hutk {
 
+// k_cut's notes from a tile (rare, out of line so that the hot path does not carry them): no word start of the
+// reference's own among the tile's positions -> its bit in noreal_bits; starts, but none in the halo -> this may be the
+// tile in front of a run, and its last start is where k_cut would cut: 1 + position into *cutpos (LDS; the ids in front
+// of it are counted in the epilogue).
+__device__ __noinline__ void cut_note_cold(uint32_t* noreal_bits, uint32_t* counters, uint32_t tile, unsigned long long mine,
+                                                  uint32_t last16, uint32_t* cutpos) {
+    // (the two pointers, not the Workspace: a structure passed by value to a function that is not inlined travels through
+    // the stack, i.e. scratch memory -- and a kernel that declares scratch makes the queue drain and set it up at its launch)
+    if ((threadIdx.x & 63) != 0) return;
+    if (mine == 0) {
+        atomicOr(&noreal_bits[tile >> 5], 1u << (tile & 31));
+        atomicAdd(&counters[6], 1u);
+    } else {  // last16: the starts (without seams) of the tile's last lane that has one
+        *cutpos = 1u + (uint32_t)(16 * (63 - __builtin_clzll(mine)) + 31 - __builtin_clz(last16 & 0xFFFFu));
+    }
+}
+
+// Out of line on purpose (the hot path of every tile does not carry it).  The per-position form indexes its window
+// dynamically: the window goes to LDS (`tmp`: 8 dwords of the calling lane's own) rather than to a stack array, which
+// would be scratch memory.
+struct Win8 { uint32_t d[8]; };  // by value: the window travels in registers
+__device__ __noinline__ uint32_t classify16_exact_cold(Win8 w, uint32_t dbits, uint32_t* tmp) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) tmp[i] = w.d[i];
+    return classify16_exact(*reinterpret_cast<const uint32_t(*)[8]>(tmp), dbits);
+}
+
 
 // ------------------------------------------------------------------------
 // k_pre
@@ -60,16 +87,20 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
     // what the kernels behind this one add to or publish in: error word, counters, per-document status, scan states
     // (here rather than in memsets of their own: a batch is a handful of launches)
     if (t == 0) *A.err = 0;
-    if (t < 16 && t != 10) W.counters[t] = 0;  // ([10]: the sample below adds to it from every workgroup; zeroed by the host's memset in front of this launch)
+    if (t < 16 && t != 10) W.counters[t] = 0;  // ([10]: the sample below adds to it from every workgroup; zeroed for the next batch by k_scan / k_tail_small, behind the tile kernels that read it)
     const int64_t n_threads = (int64_t)gridDim.x * blockDim.x;
     if (A.status)
         for (int64_t d = t; d < A.n_docs; d += n_threads) A.status[d] = 0;
     for (int64_t b = t; b < W.n_scan_blocks; b += n_threads) W.scan_state[b] = 0;
     for (int64_t b = t; b < (A.n_tiles + 31) / 32; b += n_threads) W.noreal_bits[b] = 0;
-    // which tile kernel this batch is for (Workspace::select): 16 bytes from the middle of every tile, how many of them are
-    // lead bytes of three- and four-byte characters (text in which they are many is cut into short words by the seams,
-    // most of them no tokens of a Latin-trained vocabulary: a merge-loop word every few bytes)
-    {
+    // which tile kernel this batch is for (Workspace::select): 16 bytes from the middle of the tiles of every
+    // SELECT_BLOCK_STRIDE-th workgroup, how many of them are lead bytes of three- and four-byte characters (text in which
+    // they are many is cut into short words by the seams, most of them no tokens of a Latin-trained vocabulary: a
+    // merge-loop word every few bytes).  One atomic per sampling workgroup: adds to one address queue up at ~12 ns each.
+    if (blockIdx.x % SELECT_BLOCK_STRIDE == 0) {  // (uniform)
+        __shared__ uint32_t s_hi;
+        if (threadIdx.x == 0) s_hi = 0;
+        __syncthreads();
         uint32_t hi = 0;
         const int64_t p = t * TILE_BYTES + TILE_BYTES / 2;
         if (t < A.n_tiles && p + SELECT_SAMPLE <= A.n_bytes) {
@@ -79,7 +110,9 @@ __global__ void k_pre(BatchArgs A, Workspace W) {
                             __popc(v.z & (v.z << 1) & (v.z << 2) & K) + __popc(v.w & (v.w << 1) & (v.w << 2) & K));
         }
         for (int o = 32; o; o >>= 1) hi += (uint32_t)__shfl_xor((int)hi, o, 64);
-        if ((threadIdx.x & 63) == 0 && hi) atomicAdd(&W.counters[10], hi);
+        if ((threadIdx.x & 63) == 0 && hi) atomicAdd(&s_hi, hi);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_hi) atomicAdd(&W.counters[10], s_hi);
     }
     if (t >= A.n_tiles) return;
     const int64_t gw = t * TILE_BYTES - LOOKBACK;
@@ -361,11 +394,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
                 flags = classify16_dfa(dw, dbits, reinterpret_cast<const uint16_t*>(s_m.c.dfa), s_m.c.lut,
                                        &exotic);                   // the automaton: one LDS lookup per byte
             }
-            if (exotic) {  // overlong encodings: per-position decode
+            if (exotic && !HUTK_LAB_NO_COLD) {  // overlong encodings: per-position decode
                 Win8 w8;
     #pragma unroll
                 for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
-                flags = classify16_exact_cold(w8, dbits);
+                flags = classify16_exact_cold(w8, dbits, reinterpret_cast<uint32_t*>(S) + 8 * lane);  // (the tile's symbols are not written yet: 32 bytes of LDS per lane)
             }
             // The reference ends a document at a word of more than 262144 bytes (core.c:402-407).  With seams such a word can
             // be a run of short ones here, so k_cut looks for what every such word leaves behind: at least 272 tiles in
@@ -451,8 +484,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             // whose positions are data of this tile: a last lane that is only partly data counts whole, which can only leave
             // the batch's last tile unmarked, and k_cut counts whole tiles.  Both cases are rare and live out of line.
             const unsigned long long mine = with_start & ((1ull << ((limit + 15) >> 4)) - 1ull);
-            if (mine == 0 || (with_start >> 60) == 0)
-                cut_note_cold(W, (uint32_t)tile, mine, last_real16, &me.cutpos);
+            if (!HUTK_LAB_NO_COLD && (mine == 0 || (with_start >> 60) == 0))
+                cut_note_cold(W.noreal_bits, W.counters, (uint32_t)tile, mine, last_real16, &me.cutpos);
         }
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
         uint32_t rest = own;  // my word starts that the general rounds below take
@@ -2480,6 +2513,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan(BatchArgs A, Workspace W)
     __shared__ int64_t s_base, s_ticket;
     const int tid = threadIdx.x;
     if (tid == 0) s_ticket = (int64_t)atomicAdd(&W.counters[7], 1u);
+    if (tid == 0 && blockIdx.x == 0) W.counters[10] = 0;  // k_pre's sample of this batch has been read by the tile kernels: zero for the next one
     __syncthreads();
     const int64_t blk = s_ticket;
     const int64_t base = blk * SCAN_BLOCK + (int64_t)tid * SCAN_PER_THREAD;
@@ -2866,6 +2900,7 @@ __global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Wor
         d_exc(T, A, W, 0, 1, lds);
         stage_done();
     }
+    if (lane == 0) W.counters[10] = 0;  // (k_pre's sample: zero for the next batch, as k_scan does)
     // exclusive scan of the tiles' id counts (at most SMALL_TILES <= 64)
     {
         uint32_t total;

@@ -34,6 +34,9 @@
 #ifndef HUTK_LAB_POOL_UNITS
 #define HUTK_LAB_POOL_UNITS 32  // = LANE_MAX_UNITS; lower: words of more units leave k_tiles' pool for the exception kernels (profiles/r04_pool_unit_sweep.txt)
 #endif
+#ifndef HUTK_LAB_NO_COLD
+#define HUTK_LAB_NO_COLD 0  // 1: MEASUREMENT ONLY (wrong for overlong encodings and over-long words): k_tiles without its two out-of-line calls, i.e. without scratch memory -- what does declaring scratch cost a launch?
+#endif
 #define HUTK_STR2(x) #x
 #define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD

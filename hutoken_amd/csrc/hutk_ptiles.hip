@@ -415,11 +415,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
             bool exotic;
             flags = classify16_dfa2(dw, dbits, reinterpret_cast<const uint16_t*>(s_dfa), s_dfa + dfa::TABLE_BYTES, &exotic);  // (two walks side by side: a shorter chain)
-            if (exotic) {  // overlong encodings: per-position decode
-                Win8 w8;
+            if (exotic) {
+                // overlong encodings: per-position decode.  Its window lives in LDS meanwhile (the slot's symbols are not written
+                // yet): the decode indexes it dynamically, which in registers means scratch memory -- and a launch whose scratch
+                // size differs from its predecessor's makes the queue drain first (~40 us when this kernel only looks and returns).
+                uint32_t* const tmp = reinterpret_cast<uint32_t*>(S) + 8 * lane;
 #pragma unroll
-                for (int i = 0; i < 8; i++) w8.d[i] = dw[i];
-                flags = classify16_exact_cold(w8, dbits);
+                for (int i = 0; i < 8; i++) tmp[i] = dw[i];
+                flags = classify16_exact(*reinterpret_cast<const uint32_t(*)[8]>(tmp), dbits);
             }
             // (k_cut, below: the lanes with a word start of the reference's own, and the starts of the last such lane of the tile)
             with_start = __ballot(flags != 0);
@@ -488,8 +491,16 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         {
             // k_cut's notes (see k_tiles): tiles without a word start of the reference's own; both cases are rare
             const unsigned long long minel = with_start & ((1ull << ((limit + 15) >> 4)) - 1ull);
-            if (minel == 0 || (with_start >> 60) == 0)
-                cut_note_cold(W, (uint32_t)tile, minel, last_real16, &me.cutpos);
+            if (minel == 0 || (with_start >> 60) == 0) {
+                if (lane == 0) {
+                    if (minel == 0) {
+                        atomicOr(&W.noreal_bits[tile >> 5], 1u << (tile & 31));
+                        atomicAdd(&W.counters[6], 1u);
+                    } else {  // last_real16: the starts (without seams) of the tile's last lane that has one
+                        me.cutpos = 1u + (uint32_t)(16 * (63 - __builtin_clzll(minel)) + 31 - __builtin_clz(last_real16 & 0xFFFFu));
+                    }
+                }
+            }
         }
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;  // the first unit of a word always survives
         // 4a. The starts of my 16 positions by the length of their word, all sixteen at once: f32 = my starts and the next
