@@ -38,10 +38,11 @@ ctx.profile(True)
 run(); torch.cuda.synchronize()
 tb = _capi.load().hutk_debug_tile_bytes()
 n_tiles = (len(d) + tb - 1) // tb
-ph = ctx.profile_read(n_tiles)
-names = ["total", "1 stage+docs", "2 classify", "3 byte pairs", "4 bucket words", "5 merge", "6 scan+meta", "7 write ids", "8 docpos", "9 -"]
-for nme, v in zip(names, ph):
-    print(f"  {nme:18s} {v:10.0f} cyc  {100*v/ph[0]:5.1f}%")
+if not os.environ.get("HUTK_MERGE_STAMPS_BUILD"):  # (a merge-stamps build spends the ten stamps inside the merge phase: no phase table)
+    ph = ctx.profile_read(n_tiles)
+    names = ["total", "1 stage+docs", "2 classify", "3 byte pairs", "4 bucket words", "5 merge", "6 scan+meta", "7 write ids", "8 docpos", "9 -"]
+    for nme, v in zip(names, ph):
+        print(f"  {nme:18s} {v:10.0f} cyc  {100*v/ph[0]:5.1f}%")
 if os.environ.get("HUTK_MERGE_STAMPS_BUILD"):
     # a -DHUTK_MERGE_STAMPS=1 build: the stamps are inside the merge phase; per wavefront of the workgroup
     raw = ctx.profile_raw(n_tiles)[: n_tiles // 4 * 4].reshape(-1, 4, 10)
