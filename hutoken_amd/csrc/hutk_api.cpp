@@ -827,6 +827,62 @@ static int encode_device_impl(hutk_ctx* c, const uint8_t* d_bytes, const int64_t
     return HUTK_OK;
 }
 
+// A batch of at most four tiles (hutk_encode(): a sentence) in ONE launch and without a stream synchronisation: every buffer of
+// the call lives in the context's page-locked, device-mapped staging area; k_tiles<..., ONE> does the whole pipeline and
+// raises *flag, which this thread polls (the reference answers such a call in ~20 us on one core, lib.c:668-720; three launches,
+// two copies and a hipStreamSynchronize were 56-64 us).  flag 2: the batch has exception words, the tail is launched behind.
+static int encode_one_shot(hutk_ctx* c, const uint8_t* m_bytes, const int64_t* m_offsets, int64_t n_docs, int64_t n_bytes,
+                           int32_t* m_ids, int64_t ids_cap, int64_t* m_oo, int32_t* m_status, int32_t* m_err, int32_t* m_flag) {
+    hipStream_t s = c->stream;
+    if (c->busy_valid) HIP_TRY(hipStreamWaitEvent(s, c->ev_busy, 0));
+    struct BusyMark {
+        hutk_ctx* c; hipStream_t s;
+        ~BusyMark() { if (hipEventRecord(c->ev_busy, s) == hipSuccess) c->busy_valid = true; }
+    } busy_mark{c, s};
+    const int64_t n_tiles = (n_bytes + TILE_BYTES - 1) / TILE_BYTES;
+    Workspace W{};
+    int rc = ensure_workspace(c, n_bytes, n_docs, n_tiles, W);
+    if (rc) return rc;
+    BatchArgs A{};
+    A.bytes = m_bytes;
+    A.offsets = m_offsets;
+    A.n_docs = n_docs;
+    A.n_bytes = n_bytes;
+    A.n_tiles = n_tiles;
+    A.ids_out = m_ids;
+    A.ids_cap = ids_cap;
+    A.out_offsets = m_oo;
+    A.status = m_status;
+    A.err = m_err;
+    W.one_flag = m_flag;
+    HIP_TRY(c->s_small_in.reserve((((size_t)n_docs + 1) * 8 + 15 + (size_t)n_bytes + 15 + 64)));
+    W.one_in = c->s_small_in.p;
+    c->ev_valid = false;
+    __atomic_store_n(m_flag, 0, __ATOMIC_RELEASE);
+    launch_one_shot(c->dt, A, W, s);
+    HIP_TRY(hipGetLastError());
+    int32_t f = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; (f = __atomic_load_n(m_flag, __ATOMIC_ACQUIRE)) == 0; spins++) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xFFFFu) == 0xFFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            HIP_TRY(hipStreamSynchronize(s));  // (a failed launch shows here; a kernel that ended without raising the flag cannot happen)
+            f = __atomic_load_n(m_flag, __ATOMIC_ACQUIRE);
+            if (f == 0) return set_err(HUTK_E_DEVICE, "the one-launch encode did not complete");
+            break;
+        }
+    }
+    if (f == 2) {  // exception words: their stages, the scan and the copy-out behind the tile kernel
+        W.one_flag = nullptr;
+        launch_tail_small(c->dt, A, W, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return HUTK_OK;
+}
+
 int hutk_last_timing(hutk_ctx* c, float* ms_tile_kernel, float* ms_total) {
     if (!c || !c->ev_valid) return set_err(HUTK_E_ARG, "no timed call yet");
     HIP_TRY(hipEventSynchronize(c->ev[3]));
@@ -1410,8 +1466,40 @@ static int encode_batch_host(hutk_ctx* c, const uint8_t* bytes, const int64_t* o
         const size_t in_size = in_bytes + (size_t)n_bytes;
         const size_t o_oo = 0, o_err = ((size_t)n_docs + 1) * 8, o_st = o_err + 8, o_ids = (o_st + (size_t)n_docs * 4 + 15) & ~(size_t)15;
         const size_t out_size = o_ids + (size_t)need * 4;
-        if (!c->small_host) {
-            if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocDefault) != hipSuccess) c->small_host = nullptr;
+        if (!c->small_host) {  // page-locked, mapped into the device's address space, coherent (the one-launch path polls a word of it)
+            if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+                (void)hipGetLastError();
+                if (hipHostMalloc(&c->small_host, SMALL_HOST_BYTES, hipHostMallocDefault) != hipSuccess) c->small_host = nullptr;
+            }
+        }
+        // at most four tiles: everything in one launch, input read from and results written to this buffer by the kernel itself
+        static const bool one_shot_on = !(getenv("HUTK_ONE_SHOT") && atoi(getenv("HUTK_ONE_SHOT")) == 0);
+        {
+            BatchArgs probe{};
+            probe.n_tiles = (n_bytes + TILE_BYTES - 1) / TILE_BYTES;
+            constexpr size_t ONE_OUT = 64 * 1024, ONE_FLAG = SMALL_HOST_BYTES - 64;
+            if (one_shot_on && c->small_host && one_shot_takes(c->dt, probe) && in_size <= ONE_OUT && ONE_OUT + out_size <= ONE_FLAG) {
+                uint8_t* h = static_cast<uint8_t*>(c->small_host);
+                memcpy(h + in_offs, offsets, ((size_t)n_docs + 1) * 8);
+                memcpy(h + in_bytes, bytes, (size_t)n_bytes);
+                uint8_t* ho = h + ONE_OUT;
+                int rc = encode_one_shot(c, h + in_bytes, reinterpret_cast<const int64_t*>(h + in_offs), n_docs, n_bytes,
+                                         reinterpret_cast<int32_t*>(ho + o_ids), need, reinterpret_cast<int64_t*>(ho + o_oo),
+                                         reinterpret_cast<int32_t*>(ho + o_st), reinterpret_cast<int32_t*>(ho + o_err),
+                                         reinterpret_cast<int32_t*>(h + ONE_FLAG));
+                if (rc) return rc;
+                int32_t err = 0;
+                memcpy(&err, ho + o_err, 4);
+                if (err == HUTK_OK) {
+                    memcpy(out_offsets, ho + o_oo, ((size_t)n_docs + 1) * 8);
+                    const int64_t total = out_offsets[n_docs];
+                    if (total > ids_cap) return set_err(HUTK_E_CAPACITY, "ids_cap too small");
+                    if (total) memcpy(ids_out, ho + o_ids, (size_t)total * 4);
+                    if (status && n_docs) memcpy(status, ho + o_st, (size_t)n_docs * 4);
+                    return HUTK_OK;
+                }
+                // (an error: the general path below reports it)
+            }
         }
         if (c->small_host && in_size <= SMALL_HOST_BYTES && out_size <= SMALL_HOST_BYTES) {
             HIP_TRY(c->s_small_in.reserve(in_size + 64));

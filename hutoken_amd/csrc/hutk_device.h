@@ -125,6 +125,8 @@ struct Workspace {
     // least one byte in SELECT_DENSE_DIV is "dense".  select: 0 = run; 1 = run only for a dense batch (k_ptiles); 2 = run
     // only for one that is not (k_tiles).  The kernel that is not chosen returns at once.
     int32_t select;
+    uint8_t* one_in;    // k_tiles<..., ONE>: device memory for the batch's offsets and bytes (copied from the caller's host memory once)
+    int32_t* one_flag;  // k_tiles<..., ONE>: page-locked host memory; 1 = the batch's ids and offsets are in the caller's buffers, 2 = exception words: the tail is still to run
 };
 constexpr int SELECT_SAMPLE = 16, SELECT_DENSE_DIV = 8, SELECT_BLOCK_STRIDE = 8;  // (k_pre: 256 tiles per workgroup)
 __device__ __forceinline__ bool select_skips(const Workspace& W, int64_t n_tiles) {
@@ -197,6 +199,9 @@ void launch_ptiles(const DevTables& t, const BatchArgs& a, const Workspace& w, h
 void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s);
 int64_t scan_blocks(int64_t n_tiles);
+// a batch of at most four tiles: the whole pipeline in ONE launch (Workspace::one_flag tells the host when and how it ended)
+bool one_shot_takes(const DevTables& t, const BatchArgs& a);
+void launch_one_shot(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);
 // a batch of a few tiles: exception stages, scan and copy-out as one single-wavefront launch
 bool small_tail(const BatchArgs& a);
 void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s);

@@ -174,8 +174,18 @@ struct TileLds {
 
 // MULTI: the vocabulary has special-character replacements of several units (rare): a word that holds such an item is an
 // exception word.  A build of its own, because even as a uniform branch the test costs the ordinary kernel 2.5 %.
-template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, bool MULTI = false>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A, Workspace W) {
+template <typename RunT>
+__device__ __forceinline__ void d_gather(const DevTables& T, const BatchArgs& A, const Workspace& W, int64_t vwave);
+__device__ __forceinline__ void d_doc_off(const BatchArgs& A, const Workspace& W, int64_t vblock);
+
+// ONE: the whole pipeline of a batch of at most WAVES tiles in THIS launch (hutk_encode(): a sentence): one workgroup does what
+// k_pre does for its tiles, the tile kernel, and -- when the batch has no exception word, which is the rule -- the scan, the copy
+// of the runs to the caller's ids and the documents' offsets; then it raises Workspace::one_flag (page-locked host memory
+// the caller polls: no second and third launch, no hipStreamSynchronize).  With exception words it raises the flag with 2 and the
+// host launches k_tail_small behind it.  (The reference does such a call in ~20 us on one core, lib.c:668-720.)
+template <typename SymT, bool BYTE_MODE, bool RANK_IS_SYM, int WAVES, bool MULTI = false, bool ONE = false>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(sizeof(SymT) == 2 ? (BYTE_MODE ? (RANK_IS_SYM ? HUTK_WAVES_EU : 7) : HUTK_CHAR_EU) : 3))) void k_tiles(DevTables T, BatchArgs A_in, Workspace W) {
+    BatchArgs A = A_in;  // (ONE: its input pointers are replaced below)
     typedef TileLds<SymT, BYTE_MODE> Tile;
     constexpr int ARENA_WORDS = Tile::ARENA_WORDS, ARENA_W = Tile::ARENA_W;
     constexpr int POOL_CAP = 64 * WAVES;
@@ -221,6 +231,20 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     // The wavefront's index is uniform, and told so the compiler keeps what derives from it in scalar registers: 6 vector
     // registers fewer and no spill in byte-encoder mode (+1 %); outside it the extra scalar work costs 2 %, so not there.
     if (select_skips(W, A.n_tiles)) return;  // (both tile kernels are enqueued and this batch is the other one's; uniform)
+    if constexpr (ONE) {
+        // The batch's offsets and bytes are in the caller's page-locked host memory (offsets, then -- 16-byte aligned -- the
+        // bytes): copied into device memory ONCE, every later read of them would be a round trip over PCIe (five in a row
+        // for a one-tile batch: ~8 us of a 27 us launch).
+        const size_t off_bytes = (((size_t)A.n_docs + 1) * 8 + 15) & ~(size_t)15;
+        const size_t n16 = (off_bytes + (size_t)A.n_bytes + 15) / 16;
+        const uint4* src = reinterpret_cast<const uint4*>(A.offsets);
+        uint4* dst = reinterpret_cast<uint4*>(W.one_in);
+        for (size_t i = threadIdx.x; i < n16; i += 64 * WAVES) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __syncthreads();
+        A.offsets = reinterpret_cast<const int64_t*>(W.one_in);
+        A.bytes = W.one_in + off_bytes;
+    }
     const int lane = threadIdx.x & 63;
     const int wv = BYTE_MODE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x >> 6);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Workgroup b works on
@@ -282,7 +306,26 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     const int64_t gw = t0 - LOOKBACK;  // global offset of window index 0
     const uint32_t* wmask32 = reinterpret_cast<const uint32_t*>(wmask16);
     const int64_t tile_end = (t0 + TILE_BYTES < A.n_bytes) ? t0 + TILE_BYTES : A.n_bytes;
-    const int64_t dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
+    int64_t dfirst = 0;
+    if constexpr (ONE) {
+        // what k_pre does: the error word, the counters, the documents' status (used behind the barrier below), and the first
+        // document that can touch my tile: the number of documents that begin in front of the tile's window
+        if (threadIdx.x == 0) { *A.err = 0; W.noreal_bits[0] = 0; }
+        if (threadIdx.x < 16) W.counters[threadIdx.x] = 0;
+        if (A.status)
+            for (int64_t d = threadIdx.x; d < A.n_docs; d += 64 * WAVES) A.status[d] = 0;
+        if (tile_ok) {
+            int64_t cnt = 0;
+            for (int64_t d0 = 0; d0 <= A.n_docs; d0 += 64) {
+                const int64_t d = d0 + lane;
+                cnt += __popcll(__ballot(d <= A.n_docs && A.offsets[d] < gw));
+            }
+            dfirst = cnt;
+            if (lane == 0) W.tile_first_doc[tile] = cnt;
+        }
+    } else {
+        dfirst = tile_ok ? W.tile_first_doc[tile] : 0;
+    }
     uint32_t own = 0;  // word starts of my 16 positions that are words of this tile
     // The tile's bytes are requested BEFORE the automaton's table is copied, and the offsets of its first documents before
     // that copy is waited for: one memory round trip for the three instead of three in a row (the kernel is bound by
@@ -490,7 +533,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
         reinterpret_cast<uint16_t*>(livem)[lane] = (uint16_t)own;
         uint32_t rest = own;  // my word starts that the general rounds below take
         if constexpr (BYTE_MODE && !MULTI) {
-            if (!A.word_bits && HUTK_LAB_SLIM_ROUNDS) {  // (uniform)
+            if (!A.word_bits && (HUTK_LAB_SLIM_ROUNDS || ONE)) {  // (uniform; in the one-launch kernel, where a round's length IS the call's latency: 1.5 k cycles a round less)
                 // SHORT words first, in rounds that do nothing else.  The starts of my 16 positions by the length of their word,
                 // all sixteen at once: f32 = my starts and the next lane's; x: bit j = a start among positions j + 1 .. j +
                 // WORD_KEY, i.e. the word at j is at most WORD_KEY bytes (the key of the whole-word table) and ends inside the
@@ -1160,7 +1203,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     }
     if (tile_ok) HUTK_STAMP(5);
 
-    if (!tile_ok) return;
+    if (!ONE && !tile_ok) return;
+    if (tile_ok) {
     // ---- 7. per-position epilogue: counts -> scan -> symbols out, exception records ----
     // A lane's ids are the surviving units at ITS 16 positions (whichever word they belong to: units sit
     // inside their word's byte span, so position order is id order), plus -- non-byte mode with a prefix
@@ -1305,6 +1349,32 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
     }
     HUTK_STAMP(8);
     HUTK_STAMP(9);
+    }
+    if constexpr (ONE) {
+        // ---- 9. the rest of the pipeline (k_scan, k_finish), by this workgroup ----
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");  // (the tiles' runs and counts, written by the four wavefronts, read below by other lanes)
+        __syncthreads();
+        if (__hip_atomic_load(&W.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            // exception words: their kernels are not in this launch
+            if (threadIdx.x == 0) __hip_atomic_store(W.one_flag, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        if (threadIdx.x < 64) {  // exclusive scan of the tiles' id counts (at most WAVES <= 64)
+            uint32_t total;
+            const uint32_t mine = threadIdx.x < A.n_tiles ? W.tile_count[threadIdx.x] : 0u;
+            const uint32_t before = wave_excl_scan(mine, (int)threadIdx.x, &total);
+            if (threadIdx.x < A.n_tiles) W.tile_base[threadIdx.x] = before;
+            if (threadIdx.x == 0) W.tile_base[A.n_tiles] = total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __syncthreads();
+        static_assert(WAVES <= 4, "one wavefront copies the runs of four tiles");
+        if (wv == 0) d_gather<SymT>(T, A, W, 0);
+        for (int64_t vb = 0; vb * (64 * WAVES) <= A.n_docs; vb++) d_doc_off(A, W, vb);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");  // system scope: ids, offsets, status and error word are in the caller's host memory
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(W.one_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------
@@ -2945,6 +3015,25 @@ void launch_tiles(const DevTables& t, const BatchArgs& a, const Workspace& w, hi
         default: HUTK_LAUNCH(uint32_t, false, false, TILE_WAVES); break;
     }
 #undef HUTK_LAUNCH
+}
+// the whole pipeline of a batch of at most TILE_WAVES tiles in one launch (k_tiles<..., ONE>); false: no such kernel for this vocabulary
+bool one_shot_takes(const DevTables& t, const BatchArgs& a) {
+    return TILE_WAVES <= 4 && a.n_tiles >= 1 && a.n_tiles <= TILE_WAVES && !t.has_multi && !a.word_bits && !a.first_bits;
+}
+void launch_one_shot(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
+#define HUTK_LAUNCH1(ST, BM, RS) hipLaunchKernelGGL((k_tiles<ST, BM, RS, TILE_WAVES, false, true>), dim3(1), dim3(64 * TILE_WAVES), 0, s, t, a, w)
+    const int variant = (t.sym16 ? 4 : 0) | (t.is_byte_encoder ? 2 : 0) | (t.rank_is_sym ? 1 : 0);
+    switch (variant) {
+        case 7: HUTK_LAUNCH1(uint16_t, true, true); break;
+        case 6: HUTK_LAUNCH1(uint16_t, true, false); break;
+        case 5: HUTK_LAUNCH1(uint16_t, false, true); break;
+        case 4: HUTK_LAUNCH1(uint16_t, false, false); break;
+        case 3: HUTK_LAUNCH1(uint32_t, true, true); break;
+        case 2: HUTK_LAUNCH1(uint32_t, true, false); break;
+        case 1: HUTK_LAUNCH1(uint32_t, false, true); break;
+        default: HUTK_LAUNCH1(uint32_t, false, false); break;
+    }
+#undef HUTK_LAUNCH1
 }
 bool small_tail(const BatchArgs& a) { return a.n_tiles <= SMALL_TILES && a.n_docs <= 4096; }
 void launch_tail_small(const DevTables& t, const BatchArgs& a, const Workspace& w, hipStream_t s) {
