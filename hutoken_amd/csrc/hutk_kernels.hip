@@ -1567,6 +1567,128 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
 }
 
 
+// minimum over the wavefront of a 32-bit key, in every lane (the scan's DPP pattern; lane 63's value read back)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The merge rule for ONE word of 2..EXC_LDS_UNITS units held in LDS, by one wavefront -- the form for vocabularies whose
+// rank is the symbol order (T.rank_is_sym); round 4: about half the time per merge of bpe_wave_big, which it replaces there.
+//   Sl[i] = symbol (20 bits) | index of the NEXT live unit << 20 (11 bits, FL_NONE: none) | dead << 31
+//   Ml[i] = merged symbol of (unit i, next live unit) (20 bits, PAIR_ABSENT: no rank) | index of the PREVIOUS live unit << 20
+//   l1[c] = smallest key  merged symbol << 10 | index  among the 64 units of chunk c (all ones: none)
+// A merge: the smallest key over the chunks (one read, one DPP reduction); its neighbours by following the links -- three
+// dependent LDS reads that every lane makes at the same address, where bpe_wave_big scanned for live units with ballots;
+// lanes 0 and 1 ask the pair table for the two new pairs; while those loads fly the (at most three) chunks the merge touched
+// are searched again without the entries that are about to change, which are folded in when the loads are back.  No workgroup
+// barrier: one wavefront, LDS in program order.
+constexpr uint32_t FL_NONE = 0x7FFu, FL_SYM = 0xFFFFFu, FL_DEAD = 0x80000000u;
+static_assert(EXC_LDS_UNITS <= 1024, "ten bits of position in the key, eleven in the links");
+__device__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml, uint32_t* l1, int n, int lane) {
+    constexpr uint32_t NOKEY = 0xFFFFFFFFu;
+    const int NC = (n + 63) >> 6;
+    // links and the pair results of neighbours, every unit at once
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        uint32_t s0 = 0, s1 = 0;
+        if (i < n) s0 = Sl[i] & FL_SYM;
+        if (i + 1 < n) s1 = Sl[i + 1] & FL_SYM;
+        wave_sync();  // (every lane has read its neighbour's plain symbol before anybody adds the link bits)
+        if (i < n) {
+            const uint32_t m = (i + 1 < n) ? pair_lookup(T, s0, s1) : SYM_NONE;
+            Sl[i] = s0 | ((i + 1 < n ? (uint32_t)(i + 1) : FL_NONE) << 20);
+            Ml[i] = (m == SYM_NONE ? PAIR_ABSENT : m) | ((i > 0 ? (uint32_t)(i - 1) : FL_NONE) << 20);
+        }
+    }
+    wave_sync();
+    auto chunk_key = [&](int c, uint32_t skip_a, uint32_t skip_b) -> uint32_t {  // smallest key of chunk c, two positions left out
+        const uint32_t i = (uint32_t)(64 * c + lane);
+        uint32_t k = NOKEY;
+        if ((int)i < n && i != skip_a && i != skip_b) {
+            const uint32_t m = Ml[i] & FL_SYM;
+            if (m != PAIR_ABSENT) k = (m << 10) | i;
+        }
+        return wave_min_u32(k);
+    };
+    for (int c = 0; c < NC; c++) {
+        const uint32_t k = chunk_key(c, NOKEY, NOKEY);
+        if (lane == 0) l1[c] = k;
+    }
+    wave_sync();
+    int left = n;
+    for (;;) {
+        const uint32_t best = wave_min_u32(lane < NC ? l1[lane] : NOKEY);
+        if (best == NOKEY) break;
+        const uint32_t p = best & 1023u, merged = best >> 10;
+        const uint32_t sp = Sl[p], mp = Ml[p];
+        const uint32_t q = (sp >> 20) & FL_NONE, p0 = (mp >> 20) & FL_NONE;  // the unit the merge consumes (there is one), the unit in front (or none)
+        const uint32_t sq = Sl[q];
+        const uint32_t sl0 = p0 != FL_NONE ? Sl[p0] : 0u;
+        const uint32_t q2 = (sq >> 20) & FL_NONE;  // the unit behind the consumed one (or none)
+        const uint32_t sr0 = q2 != FL_NONE ? Sl[q2] : 0u;
+        const uint32_t mp0 = p0 != FL_NONE ? Ml[p0] : 0u, mq2 = q2 != FL_NONE ? Ml[q2] : 0u;
+        // the two new pairs: lane 0 asks for (merged, right neighbour), lane 1 for (left neighbour, merged)
+        uint32_t lk = SYM_NONE;
+        const bool ask = (lane == 0 && q2 != FL_NONE) || (lane == 1 && p0 != FL_NONE);
+        PairProbe pr{};
+        const uint32_t pl = lane == 0 ? merged : (sl0 & FL_SYM), prr = lane == 0 ? (sr0 & FL_SYM) : merged;
+        if (ask) pr = pair_issue(T, pl, prr);
+        // the merge itself
+        wave_sync();
+        if (lane == 0) {
+            Sl[p] = merged | (q2 << 20);
+            Sl[q] = FL_DEAD;
+            Ml[q] = PAIR_ABSENT | (FL_NONE << 20);
+            if (q2 != FL_NONE) Ml[q2] = (mq2 & FL_SYM) | (p << 20);
+        }
+        left--;
+        wave_sync();
+        // the chunks the merge touched, without p and p0 (their pairs are being looked up) -- q is dead: its entry reads "no rank"
+        const int cp = (int)(p >> 6), cq = (int)(q >> 6), c0 = p0 != FL_NONE ? (int)(p0 >> 6) : cp;
+        uint32_t kp = chunk_key(cp, p, p0);
+        uint32_t kq = cq != cp ? chunk_key(cq, p, p0) : NOKEY;
+        uint32_t k0 = (c0 != cp && c0 != cq) ? chunk_key(c0, p, p0) : NOKEY;
+        if (ask) lk = pair_resolve(T, pr, pl, prr);
+        const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)lk, 0), ml = (uint32_t)__builtin_amdgcn_readlane((int)lk, 1);
+        const uint32_t mrf = (q2 != FL_NONE && mr != SYM_NONE) ? mr : PAIR_ABSENT;
+        const uint32_t mlf = (p0 != FL_NONE && ml != SYM_NONE) ? ml : PAIR_ABSENT;
+        const uint32_t key_r = mrf != PAIR_ABSENT ? ((mrf << 10) | p) : NOKEY;
+        const uint32_t key_l = mlf != PAIR_ABSENT ? ((mlf << 10) | p0) : NOKEY;
+        kp = min(kp, key_r);
+        if (c0 == cp) kp = min(kp, key_l);
+        else if (c0 == cq) kq = min(kq, key_l);
+        else k0 = min(k0, key_l);
+        if (lane == 0) {
+            Ml[p] = mrf | (p0 << 20);
+            if (p0 != FL_NONE) Ml[p0] = mlf | (mp0 & ~FL_SYM);
+            l1[cp] = kp;
+            if (cq != cp) l1[cq] = kq;
+            if (c0 != cp && c0 != cq) l1[c0] = k0;
+        }
+        wave_sync();
+    }
+    // the survivors to the front as plain symbols, 64 units at a time (writes never pass the reads)
+    int out = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t e = i < n ? Sl[i] : FL_DEAD;
+        const bool live = !(e & FL_DEAD);
+        const unsigned long long bal = __ballot(live);
+        wave_sync();
+        if (live) Sl[out + __popcll(bal & ((1ull << lane) - 1ull))] = e & FL_SYM;
+        out += __popcll(bal);
+        wave_sync();
+    }
+    (void)left;
+    return out;
+}
+
 // document holding byte ws of tile `tile`: last d with offsets[d] <= ws.  The tile metadata brackets it
 // (tile_first_doc = first document at or after the tile start - LOOKBACK), so the search is two or three
 // probes instead of log2(n_docs).
@@ -2480,7 +2602,9 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         // marks and per-chunk best keys as the words in HBM (chunks of 64 units, at most 16 of them: a merge costs three
         // chunk rescans instead of a shift of half the word, barriers and all)
         __shared__ uint32_t s_l1[2 * (EXC_LDS_UNITS / 64)];
+        const bool fast = in_lds && T.rank_is_sym && n >= 2 && HUTK_LAB_EXC_FAST;  // (rank == symbol order: 32-bit keys, bpe_wave_fast)
         const int64_t left = !in_lds ? bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane)
+                           : fast ? bpe_wave_fast(T, Sl, Ml, s_l1, (int)n, lane)
                            : n > EXC_SHIFT_MAX ? bpe_wave_big(T, Sl_a, Ml_a, s_l1, s_l1 + EXC_LDS_UNITS / 64, n, lane)
                                                : bpe_wave(T, Sl_a, Ml_a, n, lane);
         const int na = alone ? T.n_prefix_alone : 0;

@@ -37,6 +37,9 @@
 #ifndef HUTK_LAB_NO_COLD
 #define HUTK_LAB_NO_COLD 0  // 1: MEASUREMENT ONLY (wrong for overlong encodings and over-long words): k_tiles without its two out-of-line calls, i.e. without scratch memory -- what does declaring scratch cost a launch?
 #endif
+#ifndef HUTK_LAB_EXC_FAST
+#define HUTK_LAB_EXC_FAST 1  // 0: words of up to 1024 units merge with round 3's bpe_wave / bpe_wave_big (A/B of bpe_wave_fast)
+#endif
 #define HUTK_STR2(x) #x
 #define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD
