@@ -324,3 +324,30 @@ def test_g11_cjk_dense_vocabulary():
         assert res[:len(g["first"])] == g["first"]
         assert int(oo[-1]) == g["n_ids"]
         assert sha_ids(res) == g["sha256"]
+
+
+def test_batches_the_persistent_tile_kernel_is_chosen_for(oracle_mod):
+    """A batch of a few thousand tiles dense in three-byte characters: the default mode enqueues both tile kernels and the
+    sample k_pre takes of the batch makes k_ptiles the one that runs (hutk_api.cpp, Workspace::select); mixed text of the same
+    size goes to k_tiles.  Every id of both against the oracle, and both again with each kernel forced."""
+    import os
+    from hutoken_amd import data, synth
+    vp, sp, kw = data.vocab_files("VG")
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    for gen in (lambda: synth.cjk_paragraphs(3000), lambda: synth.corpus("C3", 12000)):
+        d, o = gen()
+        assert (len(d) + 959) // 960 >= 2048
+        ids_o, oo_o, _ = orc.encode_packed(d, o, 8)
+        for mode in (None, "0", "1"):
+            old = os.environ.pop("HUTK_PTILES", None)
+            if mode is not None:
+                os.environ["HUTK_PTILES"] = mode
+            try:
+                ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+                ids, oo, st, rc = ctx.encode_packed(d, o)
+            finally:
+                os.environ.pop("HUTK_PTILES", None)
+                if old is not None:
+                    os.environ["HUTK_PTILES"] = old
+            assert rc == 0
+            assert np.array_equal(oo, oo_o) and np.array_equal(ids, ids_o), mode
