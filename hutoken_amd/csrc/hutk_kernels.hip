@@ -2628,7 +2628,10 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
 //            the others: d_exc_ends, the lengths of the words whose end no tile saw, and the two lists for ...
 //   k_exc_b  workgroups [0, EXB_QUAD): d_exc_quad, sixteen lanes per word; the others: d_exc, a wavefront per word
 // The two roles of a launch share one LDS area (a role's arrays would otherwise be allocated for every workgroup).
-constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUAD = 5120, EXB_WAVE = 4096;
+#ifndef HUTK_EXB_WAVE
+#define HUTK_EXB_WAVE 4864  // (19 per CU: what the role's 8.4 KB of LDS lets a CU hold; 4096: -6 % on words of 300-900 letters)
+#endif
+constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUAD = 5120, EXB_WAVE = HUTK_EXB_WAVE;
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 template <typename SymT>
 __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspace W, uint32_t n_medium) {
