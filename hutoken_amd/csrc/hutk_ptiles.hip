@@ -41,6 +41,9 @@ namespace hutk {
 #ifndef HUTK_PT_PERTURB_SLEEP
 #define HUTK_PT_PERTURB_SLEEP 0
 #endif
+#ifndef HUTK_PT_SWAR
+#define HUTK_PT_SWAR 0
+#endif
 #ifndef HUTK_PT_REFILL
 #define HUTK_PT_REFILL 48
 #endif
@@ -414,7 +417,11 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             const uint32_t dw[8] = {(uint32_t)w.a, (uint32_t)(w.a >> 32), (uint32_t)w.b, (uint32_t)(w.b >> 32),
                                     (uint32_t)w.c, (uint32_t)(w.c >> 32), (uint32_t)w.d, (uint32_t)(w.d >> 32)};
             bool exotic;
+#if HUTK_PT_SWAR
+            flags = classify16(dw, dbits, &exotic);  // byte-parallel mask algebra: ~650 integer instructions, NO LDS lookup
+#else
             flags = classify16_dfa2(dw, dbits, reinterpret_cast<const uint16_t*>(s_dfa), s_dfa + dfa::TABLE_BYTES, &exotic);  // (two walks side by side: a shorter chain)
+#endif
             if (exotic) {
                 // overlong encodings: per-position decode.  Its window lives in LDS meanwhile (the slot's symbols are not written
                 // yet): the decode indexes it dynamically, which in registers means scratch memory -- and a launch whose scratch
