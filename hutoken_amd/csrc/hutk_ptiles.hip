@@ -41,13 +41,20 @@ namespace hutk {
 #ifndef HUTK_PT_PERTURB_SLEEP
 #define HUTK_PT_PERTURB_SLEEP 0
 #endif
+#ifndef HUTK_PT_MARKS
+#define HUTK_PT_MARKS 0
+#endif
 #ifndef HUTK_PT_SWAR
 #define HUTK_PT_SWAR 0
 #endif
 #ifndef HUTK_PT_REFILL
 #define HUTK_PT_REFILL 48
 #endif
+#if HUTK_PT_MARKS  // (tools/ptiles_isa.py builds with -DHUTK_PT_MARKS=1: comments in the ISA between which it counts instructions)
 #define PT_MARK(name) asm volatile("; PTMARK " name)
+#else
+#define PT_MARK(name) do {} while (0)
+#endif
 constexpr int PT_WAVES = HUTK_PT_WAVES;       // wavefronts of the one workgroup a compute unit holds
 #ifndef HUTK_PT_WGS
 #define HUTK_PT_WGS 1  // workgroups per compute unit (2: eight wavefronts per SIMD, 64 VGPRs, half the LDS each)

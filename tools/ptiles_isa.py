@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "hutoken_amd", "csrc", "hutk_ptiles.hip")
 out = "/tmp/ptiles_isa.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(root, "include"),
-                       "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:], stderr=subprocess.DEVNULL)
+                       "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-DHUTK_PT_MARKS=1", "-o", out, src] + sys.argv[1:], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4hutk8k_ptiles"))
 cur = "prologue"
