@@ -92,6 +92,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// __syncthreads() of a workgroup that is ONE wavefront, without the s_barrier: the same fences, so that what one lane wrote
+// (LDS or global memory) the others read afterwards -- for code that also runs as one of two independent wavefronts of a
+// workgroup (k_exc_b), where an s_barrier would tie them together.
+__device__ __forceinline__ void wave_wg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ __forceinline__ void raise(int32_t* err, int32_t code) { atomicCAS(err, 0, code); }
 
 // Is the word at byte ws (of the document that starts at ds) the one the prefix goes with (core.c:364-366, 421-451: the

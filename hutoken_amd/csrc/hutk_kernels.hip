@@ -1422,7 +1422,7 @@ template <class Arr>
 __device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int lane) {
     for (int64_t i = lane; i < n; i += 64)
         Ma.set(i, (i + 1 < n) ? pair_lookup(T, Sa.get(i), Sa.get(i + 1)) : SYM_NONE);
-    __syncthreads();
+    wave_wg_sync();
     while (n > 1) {
         uint64_t best = ~0ull;
         for (int64_t i = lane; i + 1 < n; i += 64) {
@@ -1439,7 +1439,7 @@ __device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int l
         const bool has_left = p > 0, has_right = p + 2 < n;
         const uint32_t sl = has_left ? Sa.get(p - 1) : 0u;
         const uint32_t sr = has_right ? Sa.get(p + 2) : 0u;
-        __syncthreads();
+        wave_wg_sync();
         for (int64_t base = p + 1; base + 1 < n; base += 64) {
             const int64_t i = base + lane;
             uint32_t s = 0, m = 0;
@@ -1448,12 +1448,12 @@ __device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int l
                 s = Sa.get(i + 1);
                 m = Ma.get(i + 1);
             }
-            __syncthreads();
+            wave_wg_sync();
             if (on) {
                 Sa.set(i, s);
                 Ma.set(i, m);
             }
-            __syncthreads();
+            wave_wg_sync();
         }
         n -= 1;
         if (lane == 0) {
@@ -1461,7 +1461,7 @@ __device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int l
             Ma.set(p, has_right ? pair_lookup(T, merged, sr) : SYM_NONE);
         }
         if (lane == 1 && has_left) Ma.set(p - 1, pair_lookup(T, sl, merged));
-        __syncthreads();
+        wave_wg_sync();
     }
     return n;
 }
@@ -1487,7 +1487,7 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
     const int NC = (int)((n + CH - 1) / CH);                                               // <= 1024
     for (int64_t i = lane; i < n; i += 64)
         Mg.set(i, (i + 1 < n) ? pair_lookup(T, Sg.get(i), Sg.get(i + 1)) : SYM_NONE);
-    __syncthreads();
+    wave_wg_sync();
     auto rescan = [&](int64_t c) {  // whole wavefront: best key of chunk c -> L1
         const int64_t lo = c * CH, hi = (lo + CH < n) ? lo + CH : n;
         uint64_t best = ~0ull;
@@ -1505,7 +1505,7 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
         }
     };
     for (int c = 0; c < NC; c++) rescan(c);
-    __syncthreads();
+    wave_wg_sync();
     // first live unit at or after `from` (-1: none); last live unit at or before `from` (-1: none)
     auto next_live = [&](int64_t from) -> int64_t {
         for (int64_t base = from; base < n; base += 64) {
@@ -1536,7 +1536,7 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
         const int64_t q = next_live(p + 1);  // the unit the merge consumes (exists: the pair was a candidate)
         const int64_t q2 = next_live(q + 1), p0 = prev_live(p - 1);
         const uint32_t sr = q2 >= 0 ? Sg.get(q2) : 0u, sl = p0 >= 0 ? Sg.get(p0) : 0u;
-        __syncthreads();
+        wave_wg_sync();
         if (lane == 0) {
             Sg.set(p, merged);
             Sg.set(q, UNIT_DEAD);
@@ -1544,12 +1544,12 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
             Mg.set(p, q2 >= 0 ? pair_lookup(T, merged, sr) : SYM_NONE);
         }
         if (lane == 1 && p0 >= 0) Mg.set(p0, pair_lookup(T, sl, merged));
-        __syncthreads();
+        wave_wg_sync();
         const int64_t cp = p / CH, cq = q / CH, c0 = p0 >= 0 ? p0 / CH : cp;
         rescan(cp);
         if (cq != cp) rescan(cq);
         if (c0 != cp) rescan(c0);
-        __syncthreads();
+        wave_wg_sync();
     }
     // compaction of the survivors to the front, 64 units at a time (writes never pass the reads)
     int64_t out = 0;
@@ -1558,10 +1558,10 @@ __device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1
         const uint32_t sym = i < n ? Sg.get(i) : UNIT_DEAD;
         const bool live = sym != UNIT_DEAD;
         const unsigned long long bal = __ballot(live);
-        __syncthreads();
+        wave_wg_sync();
         if (live) Sg.set(out + __popcll(bal & ((1ull << lane) - 1ull)), sym);
         out += __popcll(bal);
-        __syncthreads();
+        wave_wg_sync();
     }
     return out;
 }
@@ -1789,7 +1789,7 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
                                                 uint32_t vgrid, uint8_t* lds) {
     constexpr int UNITS = 64 * NW, ROW = UNITS + 4;
     static_assert(UNITS <= QUAD_UNITS, "the quad list holds words of up to QUAD_UNITS units");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + (lane % LANES) * ROW;
     constexpr uint32_t HI = 0xFFFF0000u;
     const uint32_t n_exc = NW == 1 ? W.counters[0] : W.counters[4];  // records, or entries of the quad list
@@ -1967,6 +1967,284 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
         }
         if (NW == 1) medium_leave(T, W, !have && idx < n_exc && (int64_t)idx < W.cap_exc && rec.len >= 1 && rec.cnt == 0, idx, lane, rec.len);
     }
+}
+
+// d_exc_lane_fast's words of 65..256 units with NW LANES PER WORD (round 4): the same rows, 32 (NW = 2: up to 128 units)
+// or 16 (NW = 4) words per wavefront -- every lane at work, where the one-lane form kept 16 / 8 of 64 busy to stay within
+// 8.4 KB.  What a lane did alone is shared out:
+//   * the row's search, 3/4 of a trip's instructions: the row is 16-unit blocks dealt round the group (lane s: blocks s,
+//     s + NW, ...: four per lane), a lane keeps the best key of each of its blocks in a register, and a trip searches again
+//     only the blocks whose dwords it changed -- at most one per lane, read at a lane-dependent address, so the wavefront
+//     runs the 16-unit search ONCE per trip whatever the words' lengths (a word whose live units lie so far apart that
+//     a lane owns two changed blocks searches all its blocks: seldom); a DPP minimum over the group ends the trip;
+//   * the liveness bits: lane s holds units 64 s .. 64 s + 63, a neighbour is a DPP minimum / maximum of the lanes' answers;
+//   * the two pair lookups of a merge: lane 0 the new right pair, lane 1 the new left one.
+// The search now follows the lookups (it reads their results) instead of running under them: with two or more
+// wavefronts per SIMD the kernel is bound by the instructions it issues, not by a trip's latency (k_exc_b with half its
+// wavefronts took the same time, profiles/r04_exc_group_ab.txt).
+template <int LPW>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {  // minimum over each group of LPW (2, 4) lanes, in every lane
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    if (LPW == 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    return v;
+}
+template <int LPW>
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
+    if (LPW == 4) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    return v;
+}
+template <int NW>
+__device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
+                                                 uint32_t vgrid, uint8_t* lds) {
+    constexpr int LPW = NW, UNITS = 64 * NW, ROW = UNITS + 4, WPW = 64 / LPW;
+    static_assert(NW == 2 || NW == 4, "groups of two or four lanes (quad_perm)");
+    static_assert(UNITS <= QUAD_UNITS, "the quad list holds words of up to QUAD_UNITS units");
+    const int lane = threadIdx.x & 63, sub = lane % LPW, w = lane / LPW;
+    uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + w * ROW;
+    constexpr uint32_t HI = 0xFFFF0000u;
+    const uint32_t n_exc = W.counters[4];  // entries of the quad list
+#if HUTK_LAB_EXC_STAMPS
+    long long st_acc[4] = {0, 0, 0, 0}, st_trips = 0, st_lots = 0;
+    const long long st_begin = clock64();
+#endif
+    for (uint32_t round = 0;; round++) {
+        uint32_t lot = vblock;
+        if (round) {
+            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[NW == 2 ? 8 : 9], 1u);
+            lot = (uint32_t)__shfl((int)lot, 0, 64);
+        }
+        const uint64_t base = (uint64_t)lot * WPW;
+        if (base >= n_exc) break;
+        const uint64_t at = base + w;
+        bool have = at < n_exc;  // (the same for a group's lanes, as everything below that does not mention sub)
+        uint64_t idx = 0;
+        if (have) idx = W.exc_quad[at];
+        ExcRec rec{};
+        if (have) rec = W.exc[idx];
+        const uint32_t rec_tile = rec.tile;  // (the record itself does not stay in registers over the trips)
+        int64_t gbase = 0;
+        int n = 0, na = 0;
+        uint64_t lv = 0;       // the lane's share of the liveness bits: units 64 sub .. 64 sub + 63
+        uint32_t bm[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // best keys of blocks sub, sub + LPW, ...
+        uint32_t best = 0xFFFFFFFFu;
+        // best key of the 16 units of block blk: four 16-byte reads in flight (the row reads "no rank" from the word's last
+        // unit to the next multiple of 16; a block behind that is not the word's: no key)
+        auto scan_block = [&](int blk) -> uint32_t {
+            uint4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = *reinterpret_cast<const uint4*>(U + 16 * blk + 4 * j);
+            uint32_t b0 = 0xFFFFFFFFu, b1 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t at = (uint32_t)(16 * blk + 4 * j);
+                b0 = min(b0, min((v[j].x & HI) | at, (v[j].y & HI) | (at + 1u)));
+                b1 = min(b1, min((v[j].z & HI) | (at + 2u), (v[j].w & HI) | (at + 3u)));
+            }
+            return 16 * blk < n ? min(b0, b1) : 0xFFFFFFFFu;
+        };
+        if (have) {
+            const int64_t ws = rec.ws;
+            const int nb = rec.len;
+            const int64_t d = doc_of(A, W, ws, rec.tile);
+            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
+            const bool with_prefix = T.has_prefix && docfirst;
+            const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
+            const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
+            na = alone ? T.n_prefix_alone : 0;
+            gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
+            if (kp + nb > UNITS || (NW == 4 && kp + nb <= UNITS / 2)) {
+                have = false;  // NW == 2: left to the NW == 4 pass (or to d_exc); NW == 4: the NW == 2 pass took it
+            } else {
+                if (sub == 0)
+                    for (int i = 0; i < kp; i++) U[i] = HI | (T.prefix_syms[i] & 0xFFFFu);
+                n = kp;
+                int looked_up = 0;  // units [0, looked_up) still need their pair result from the pair table
+                if (T.is_byte_encoder) {
+                    // eight units per step and lane (d_exc_lane_fast: sixteen -- and 40 more registers), the steps dealt round the group
+                    const uint8_t* wb = A.bytes + ws;
+                    const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
+                    for (int i0 = 8 * sub; i0 < nb; i0 += 8 * LPW) {
+                        uint32_t b[9];
+#pragma unroll
+                        for (int j = 0; j < 9; j++) b[j] = wb[min(i0 + j, nb - 1)];  // (clamped: in bounds, no branch)
+                        uint32_t e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) e[j] = bp[b[j] | (b[j + 1] << 8)];
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (i0 + j < nb) U[n + i0 + j] = (i0 + j + 1 < nb) ? e[j] : (e[j] | HI);
+                    }
+                    looked_up = n;  // (prefix units in front: their pairs, and the one into the word)
+                    n += nb;
+                } else {
+                    if (sub == 0) {  // (characters of one to four bytes: one lane walks them)
+                        for (int i = 0; i < nb;) {
+                            const uint32_t b = A.bytes[ws + i];
+                            int L = (b < 0x80u) ? 1 : (b >= 0xF0u) ? 4 : (b >= 0xE0u) ? 3 : (b >= 0xC0u) ? 2 : 1;
+                            uint32_t sym;
+                            if ((b >= 0x80u && (L == 1 || b >= 0xF8u)) || i + L > nb) {
+                                raise(A.err, HUTK_E_INVALID_UTF8);
+                                sym = SYM_UNK;
+                                L = 1;
+                            } else if (T.item_direct[b]) {
+                                sym = T.item_sym[b];
+                            } else if (L == 1) {
+                                sym = SYM_UNK;
+                            } else {
+                                uint32_t packed = b | ((uint32_t)A.bytes[ws + i + 1] << 8);
+                                if (L > 2) packed |= (uint32_t)A.bytes[ws + i + 2] << 16;
+                                if (L > 3) packed |= (uint32_t)A.bytes[ws + i + 3] << 24;
+                                sym = char_lookup(T, packed);
+                            }
+                            U[n] = HI | (sym & 0xFFFFu);
+                            n++;
+                            i += L;
+                        }
+                    }
+                    n = __shfl(n, lane - sub, 64);
+                    looked_up = n - 1;
+                }
+                for (int i0 = 4 * sub; i0 < looked_up; i0 += 4 * LPW) {  // four lookups (eight loads) in flight per lane
+                    PairProbe pr[4];
+                    uint32_t sy[5];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) sy[j] = (i0 + j < n) ? (U[i0 + j] & 0xFFFFu) : 0u;
+#pragma unroll
+                    for (int j = 0; j < 5; j++) sy[j] = sy[j] == 0xFFFFu ? SYM_UNK : sy[j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) pr[j] = pair_issue(T, sy[j], sy[j + 1]);
+                    // (a unit's dword is written by the lane that holds its step only: the next step's lane has read the
+                    // symbol it needs -- the low half, which stays -- whenever it comes by)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (i0 + j < looked_up && i0 + j + 1 < n) {
+                            const uint32_t m = pair_resolve(T, pr[j], sy[j], sy[j + 1]);
+                            U[i0 + j] = (m << 16) | (sy[j] & 0xFFFFu);  // (SYM_NONE: 0xFFFF in the upper half)
+                        }
+                }
+                if (sub == 0)
+                    for (int i = n; i < ((n + 15) & ~15); i++) U[i] = 0xFFFFFFFFu;  // the row's last reads cover them
+                const int mine_n = n - 64 * sub;
+                lv = mine_n >= 64 ? ~0ull : mine_n > 0 ? ((1ull << mine_n) - 1ull) : 0ull;
+            }
+        }
+        // (one block at a time: unrolled, the compiler keeps all sixteen reads' registers at once)
+        auto scan_all = [&]() {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                const uint32_t r = scan_block(sub + LPW * k);
+#pragma unroll
+                for (int j = 0; j < 4; j++) bm[j] = k == j ? r : bm[j];
+            }
+        };
+        if (have) {
+            scan_all();
+            best = group_min_u32<LPW>(min(min(bm[0], bm[1]), min(bm[2], bm[3])));
+        }
+#if HUTK_LAB_EXC_STAMPS
+        st_lots++;
+#endif
+        // One merge per trip and word
+        for (;;) {
+            const bool act = have && best < HI;
+            if (!__any(act)) break;
+#if HUTK_LAB_EXC_STAMPS
+            const long long st0 = clock64();
+            int st_d1 = 0, st_d2 = 0;
+#endif
+            if (act) {
+                const int p = (int)(best & 0xFFFFu);
+                const uint32_t merged = best >> 16;
+                auto first_after = [&](int x) -> int {  // first live unit behind x, or 0xFFFF
+                    const int sx = x >> 6;
+                    const uint64_t m = sub == sx ? (lv & ~((2ull << (x & 63)) - 1ull)) : sub > sx ? lv : 0ull;
+                    return (int)group_min_u32<LPW>(m ? (uint32_t)(64 * sub + __builtin_ctzll(m)) : 0xFFFFu);
+                };
+                const int q = first_after(p);  // the unit the merge consumes (there is one: the pair was a candidate)
+                if (sub == (q >> 6)) lv &= ~(1ull << (q & 63));
+                const int qn = first_after(q);
+                const int sp = p >> 6;
+                const uint64_t mb = sub == sp ? (lv & ((1ull << (p & 63)) - 1ull)) : sub < sp ? lv : 0ull;
+                const int pn = (int)group_max_u32<LPW>(mb ? (uint32_t)(64 * sub + 64 - __builtin_clzll(mb)) : 0u) - 1;  // last live unit in front of p, or -1
+                const bool right = qn != 0xFFFF, left = pn >= 0;
+                const bool mine = sub == 0 ? right : sub == 1 ? left : false;  // lane 0: the pair (p, qn), lane 1: (pn, p)
+                uint32_t a = 0, b = 0, low = 0;
+                PairProbe pr{};
+                if (mine) {
+                    const uint32_t un = U[sub == 0 ? qn : pn];
+                    uint32_t sn = un & 0xFFFFu;
+                    sn = sn == 0xFFFFu ? SYM_UNK : sn;  // (a unit that is no symbol: never a member of a pair)
+                    a = sub == 0 ? merged : sn;
+                    b = sub == 0 ? sn : merged;
+                    low = un & 0xFFFFu;
+                    pr = pair_issue(T, a, b);
+                }
+                if (sub == 0) U[q] = 0xFFFFFFFFu;
+                // which of its blocks has the lane to search again?  The changed dwords are pn's, p's and q's: blocks bl <= bp <= bq
+                const int bq = q >> 4, bl = (left ? pn : p) >> 4, bpp = p >> 4;
+                const bool wide = bq - bl >= LPW;  // (a lane may own two of them)
+                const int tb = (bq % LPW) == sub ? bq : (bpp % LPW) == sub ? bpp : (bl % LPW) == sub ? bl : sub;
+#if HUTK_LAB_EXC_STAMPS
+                st_d1 = (int)(clock64() - st0);
+#endif
+                if (sub == 0 || mine) {  // (lane 0 stores the merged symbol whether or not it has a right neighbour)
+                    const uint32_t r = pair_resolve(T, pr, a, b);
+                    const uint32_t m = mine ? r : SYM_NONE;
+                    U[sub == 0 ? p : pn] = (m << 16) | (sub == 0 ? merged : low);
+                }
+#if HUTK_LAB_EXC_STAMPS
+                st_d2 = (int)(clock64() - st0);
+#endif
+                if (wide) {
+                    scan_all();
+                } else {
+                    const uint32_t r = scan_block(tb);
+                    const int k = tb / LPW;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bm[j] = k == j ? r : bm[j];
+                }
+                best = group_min_u32<LPW>(min(min(bm[0], bm[1]), min(bm[2], bm[3])));
+            }
+#if HUTK_LAB_EXC_STAMPS
+            {
+                const int src = __builtin_ctzll(__ballot(act));
+                const long long d1 = __shfl(st_d1, src, 64), d2 = __shfl(st_d2, src, 64), d3 = clock64() - st0;
+                st_acc[0] += d1; st_acc[1] += d2 - d1; st_acc[2] += d3 - d2; st_trips++;
+            }
+#endif
+        }
+        if (have) {
+            int32_t* out = W.exc_tok + gbase;
+            if (sub == 0)
+                for (int i = 0; i < na; i++) out[i] = T.prefix_alone_ids[i];
+            // lane s: the units of its 64 liveness bits, behind those of the lanes before it
+            const int cnt = __popcll(lv);
+            int incl = cnt;  // inclusive scan over the group's lanes
+#pragma unroll
+            for (int dlt = 1; dlt < LPW; dlt *= 2) {
+                const int o = __shfl_up(incl, dlt, LPW);
+                if (sub >= dlt) incl += o;
+            }
+            const int total = na + __shfl(incl, LPW - 1, LPW);
+            int k = na + incl - cnt;
+            for (uint64_t c = lv; c; c &= c - 1) {
+                const uint32_t sy = U[64 * sub + __builtin_ctzll(c)] & 0xFFFFu;
+                out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
+            }
+            if (sub == 0) {
+                W.exc[idx].cnt = (uint32_t)total;
+                W.exc[idx].tok_base = gbase;
+                atomicAdd(&W.tile_count[rec_tile], (uint32_t)total);
+            }
+        }
+    }
+#if HUTK_LAB_EXC_STAMPS
+    if (W.prof && lane == 0 && vblock < (uint32_t)A.n_tiles) {
+        long long* o = W.prof + (size_t)vblock * 10;
+        if (NW == 2) { o[0] = clock64() - st_begin; o[1] = st_acc[0]; o[2] = st_acc[1]; o[3] = st_acc[2]; o[4] = st_trips; o[5] = st_lots; }
+    }
+#endif
 }
 
 template <typename SymT>
@@ -2168,7 +2446,7 @@ __device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {  // minimum over e
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
-    return (uint32_t)__shfl((int)v, (int)(threadIdx.x | 15), 64);  // lane 15 of the row holds it
+    return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63) | 15), 64);  // lane 15 of the row holds it
 }
 __device__ __forceinline__ uint32_t row_excl_sum(uint32_t v) {  // exclusive prefix sum inside each row of 16 lanes
     uint32_t inc = v;
@@ -2183,7 +2461,7 @@ __device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& 
                                            uint32_t vgrid, uint8_t* lds) {
     uint32_t* const Sq = reinterpret_cast<uint32_t*>(lds);
     uint32_t* const Mq = Sq + 4 * QUAD_UNITS;
-    const int lane = threadIdx.x, g = lane >> 4, l = lane & 15, gl0 = lane & 48;  // group, lane in group, its lane 0
+    const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, gl0 = lane & 48;  // group, lane in group, its lane 0
     uint32_t* Sg = Sq + g * QUAD_UNITS;
     uint32_t* Mg = Mq + g * QUAD_UNITS;
     const uint32_t n_list = W.counters[4];
@@ -2469,17 +2747,14 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
                                       uint32_t vgrid, uint8_t* lds) {
     uint32_t* const Sl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* const Ml = Sl + EXC_LDS_UNITS;
-    __shared__ uint32_t s_idx;
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;  // (k_exc_b runs two of these per workgroup, each wavefront on its own: no s_barrier in here)
     const uint32_t n_list = W.counters[5];
     for (uint32_t round = 0;; round++) {
         uint32_t li = vblock;
         if (round) {
-            if (lane == 0) s_idx = vgrid + atomicAdd(&W.counters[2], 1u);
-            __syncthreads();
-            li = s_idx;
-            __syncthreads();
+            if (lane == 0) li = vgrid + atomicAdd(&W.counters[2], 1u);
+            li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
         }
         if (li >= n_list) break;
         const uint32_t idx = W.exc_wave[li];
@@ -2596,12 +2871,13 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
                 ubase += __popcll(bal);
             }
         }
-        __syncthreads();
+        wave_wg_sync();
 
         // In LDS: short words by shifting the tail left after every merge (bpe_wave), longer ones by the same dead-unit
         // marks and per-chunk best keys as the words in HBM (chunks of 64 units, at most 16 of them: a merge costs three
         // chunk rescans instead of a shift of half the word, barriers and all)
-        __shared__ uint32_t s_l1[2 * (EXC_LDS_UNITS / 64)];
+        __shared__ uint32_t s_l1_all[2][2 * (EXC_LDS_UNITS / 64)];
+        uint32_t* const s_l1 = s_l1_all[threadIdx.x >> 6];
         const bool fast = in_lds && T.rank_is_sym && n >= 2 && HUTK_LAB_EXC_FAST;  // (rank == symbol order: 32-bit keys, bpe_wave_fast)
         const int64_t left = !in_lds ? bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane)
                            : fast ? bpe_wave_fast(T, Sl, Ml, s_l1, (int)n, lane)
@@ -2619,7 +2895,7 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
             W.exc[idx] = rec;
             atomicAdd(&W.tile_count[rec.tile], rec.cnt);
         }
-        __syncthreads();
+        wave_wg_sync();
     }
 }
 
@@ -2631,7 +2907,10 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
 #ifndef HUTK_EXB_WAVE
 #define HUTK_EXB_WAVE 4864  // (19 per CU: what the role's 8.4 KB of LDS lets a CU hold; 4096: -6 % on words of 300-900 letters)
 #endif
-constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUAD = 5120, EXB_WAVE = HUTK_EXB_WAVE;
+#ifndef HUTK_EXB_QUAD
+#define HUTK_EXB_QUAD 5120
+#endif
+constexpr int EXA_MEDIUM16 = 2560, EXA_MEDIUM32 = 1280, EXA_ENDS = 4096, EXB_QUAD = HUTK_EXB_QUAD, EXB_WAVE = HUTK_EXB_WAVE;
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 template <typename SymT>
 __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspace W, uint32_t n_medium) {
@@ -2646,21 +2925,43 @@ __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspac
 }
 // FAST: 16-bit symbols with rank == symbol order: the quad list goes to d_exc_lane_fast (one lane per word: first the words
 // of up to 128 units, then the longer ones) instead of d_exc_quad
+#if HUTK_LAB_EXC_GROUP
+constexpr size_t LANE_FAST_LDS = cmax(32 * (128 + 4) * 4, 16 * (256 + 4) * 4);  // d_exc_group_fast: 32 / 16 rows
+#else
 constexpr size_t LANE_FAST_LDS = cmax(16 * (128 + 4) * 4, 8 * (256 + 4) * 4);
+#endif
+// Workgroups of TWO wavefronts that never meet: d_exc_group_fast wants 16.5 KB of LDS for ONE wavefront (the second one of
+// its workgroups leaves at once), d_exc and d_exc_quad 8 KB per wavefront -- so a CU holds 9 of the former or 18 of the
+// latter, where one wavefront per workgroup at 16.5 KB would have halved d_exc's (measured: words of 300-900 letters
+// 6.6 -> 4.0 GB/s).  Nothing in these roles is a workgroup barrier (wave_wg_sync).
+constexpr size_t EXB_WAVE_LDS = cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4);  // per wavefront of d_exc_quad / d_exc
+constexpr int EXB_QUAD_WGS = HUTK_LAB_EXC_GROUP ? 2304 : EXB_QUAD / 2;  // (FAST: 9 per CU, the rest of the list by the device cursor)
+#ifndef HUTK_EXB_EU
+#define HUTK_EXB_EU 5
+#endif
 template <bool FAST>
-__global__ __launch_bounds__(64) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4), FAST ? LANE_FAST_LDS : 0)];
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HUTK_EXB_EU))) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * EXB_WAVE_LDS, FAST ? (HUTK_LAB_EXC_GROUP ? 1 : 2) * LANE_FAST_LDS : 0)];
     if (W.counters[0] == 0) return;
-    if (blockIdx.x < (uint32_t)EXB_QUAD) {
+    const uint32_t wv = threadIdx.x >> 6;
+    constexpr uint32_t QWGS = FAST ? EXB_QUAD_WGS : EXB_QUAD / 2;
+    if (blockIdx.x < QWGS) {
         if (FAST) {
-            d_exc_lane_fast<2, 16>(T, A, W, blockIdx.x, EXB_QUAD, lds);
+#if HUTK_LAB_EXC_GROUP
+            if (wv) return;
+            d_exc_group_fast<2>(T, A, W, blockIdx.x, QWGS, lds);
             wave_sync();
-            d_exc_lane_fast<4, 8>(T, A, W, blockIdx.x, EXB_QUAD, lds);
+            d_exc_group_fast<4>(T, A, W, blockIdx.x, QWGS, lds);
+#else
+            d_exc_lane_fast<2, 16>(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * LANE_FAST_LDS);
+            wave_sync();
+            d_exc_lane_fast<4, 8>(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * LANE_FAST_LDS);
+#endif
         } else {
-            d_exc_quad(T, A, W, blockIdx.x, EXB_QUAD, lds);
+            d_exc_quad(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * EXB_WAVE_LDS);
         }
     } else {
-        d_exc(T, A, W, blockIdx.x - EXB_QUAD, EXB_WAVE, lds);
+        d_exc(T, A, W, 2 * (blockIdx.x - QWGS) + wv, EXB_WAVE, lds + wv * EXB_WAVE_LDS);
     }
 }
 
@@ -3087,9 +3388,15 @@ __global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Wor
         for (uint32_t sub = 0; sub < ENDS_SHARE; sub++) d_exc_ends(T, A, W, sub, ENDS_SHARE, lds);
         stage_done();
         if (fast) {
+#if HUTK_LAB_EXC_GROUP
+            d_exc_group_fast<2>(T, A, W, 0, 1, lds);
+            stage_done();
+            d_exc_group_fast<4>(T, A, W, 0, 1, lds);
+#else
             d_exc_lane_fast<2, 16>(T, A, W, 0, 1, lds);
             stage_done();
             d_exc_lane_fast<4, 8>(T, A, W, 0, 1, lds);
+#endif
         } else {
             d_exc_quad(T, A, W, 0, 1, lds);
         }
@@ -3171,8 +3478,8 @@ void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& 
     // two launches, fixed grids; every wavefront pulls work until its device list runs out
     if (t.sym16) hipLaunchKernelGGL(k_exc_a<uint16_t>, dim3(EXA_MEDIUM16 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM16);
     else hipLaunchKernelGGL(k_exc_a<uint32_t>, dim3(EXA_MEDIUM32 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM32);
-    if (t.sym16 && t.rank_is_sym) hipLaunchKernelGGL(k_exc_b<true>, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
-    else hipLaunchKernelGGL(k_exc_b<false>, dim3(EXB_QUAD + EXB_WAVE), dim3(64), 0, s, t, a, w);
+    if (t.sym16 && t.rank_is_sym) hipLaunchKernelGGL(k_exc_b<true>, dim3(EXB_QUAD_WGS + EXB_WAVE / 2), dim3(128), 0, s, t, a, w);
+    else hipLaunchKernelGGL(k_exc_b<false>, dim3(EXB_QUAD / 2 + EXB_WAVE / 2), dim3(128), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {
     hipLaunchKernelGGL(k_scan, dim3((unsigned)w.n_scan_blocks), dim3(SCAN_THREADS), 0, s, a, w);

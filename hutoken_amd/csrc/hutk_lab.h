@@ -40,6 +40,12 @@
 #ifndef HUTK_LAB_EXC_FAST
 #define HUTK_LAB_EXC_FAST 1  // 0: words of up to 1024 units merge with round 3's bpe_wave / bpe_wave_big (A/B of bpe_wave_fast)
 #endif
+#ifndef HUTK_LAB_EXC_GROUP
+#define HUTK_LAB_EXC_GROUP 1  // 0: words of 65..256 units one LANE per word (d_exc_lane_fast<2>, <4>: round 3) instead of four / eight lanes
+#endif
+#ifndef HUTK_LAB_EXC_STAMPS
+#define HUTK_LAB_EXC_STAMPS 0  // 1: d_exc_group_fast<2> leaves its trips' cycle sums in the profile buffer (tools/exc_stamps.py)
+#endif
 #define HUTK_STR2(x) #x
 #define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD

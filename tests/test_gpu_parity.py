@@ -149,6 +149,37 @@ def test_giant_words(vg_files, oracle_mod):
         assert ids_g.tolist() == list(want)
 
 
+def test_words_of_65_to_256_units(vg_files, vl_files, small_byte, oracle_mod):
+    """d_exc_group_fast: two / four lanes per word, 32 / 16 words per wavefront, block minima in registers.  Every length
+    from 65 to 256 units, enough words of each kind to fill wavefronts and to leave some half empty; words that merge
+    into long tokens (live units far apart: the lane that owns two changed blocks searches all of its blocks); the
+    prefix units of a character vocabulary in front."""
+    from hutoken_amd import synth
+    rng = random.Random(65256)
+    letters = [bytes(rng.choice(b"etaoinshrdlucmfw") for _ in range(n)) for n in range(60, 262)] * 2
+    rng.shuffle(letters)
+    # words of the corpus glued together: they merge back into their tokens, a dozen bytes and more each
+    data, offs = synth.corpus("C3", 400)
+    words = [w for w in data.tobytes().split(b" ") if 8 <= len(w) <= 40]
+    words = [w for w in words if w.decode("utf-8").isalpha() and max(map(ord, w.decode("utf-8"))) < 0x250]  # (one splitter class)
+    glued = []
+    for _ in range(300):
+        w, want = b"", rng.randrange(65, 257)
+        while len(w) < want:
+            w += rng.choice(words)
+        glued.append(w[:want].decode("utf-8", "ignore").encode("utf-8"))
+    same = [bytes([c]) * n for c in b"ae" for n in (65, 128, 129, 200, 256)]
+    docs = [b" ".join(letters[i:i + 7]) for i in range(0, len(letters), 7)]
+    docs += [b" ".join(glued[i:i + 5]) for i in range(0, len(glued), 5)]
+    docs += [b"x " + w + b" y" for w in same] + letters[:40] + glued[:40]
+    vp, sp, kw = vg_files
+    _compare(_ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]), oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"]), docs, "65-256 VG")
+    vp, sp, kw = vl_files
+    _compare(_ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]), oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"]), docs, "65-256 VL")
+    for ctx, orc in small_byte:
+        _compare(ctx, orc, docs[:120], "65-256 small")
+
+
 def test_dense_word_tiles(small_byte):
     """Tiles packed with the shortest possible words: every byte a word (newlines, stray bytes), and
     two-byte words back to back (the most multi-unit words a tile can start)."""
