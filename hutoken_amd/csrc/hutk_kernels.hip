@@ -1715,20 +1715,34 @@ constexpr int MEDIUM_UNITS = 64;
 constexpr int QUAD_UNITS = 256;  // longest word of k_exc_b's quad list (d_exc_quad, d_exc_lane_fast<4>)
 // A word of known length that d_exc_medium does not take (prefix units make it longer than MEDIUM_UNITS) goes straight on
 // k_exc_quad's or k_exc's list, one atomic per wavefront and list; words of unknown length are d_exc_ends' business.
+// (The quad list is TWO lists in one array: words of up to 128 units -- prefix included, whether or not the word gets it --
+// from the front, counters[4] of them, the longer ones from the back, counters[11]: d_exc_group_fast<2> and <4> each walk
+// their own.  As one list, 800 k words of 70-120 letters were walked a second time, 50 k lots of a cursor atomic and
+// two dependent loads each, to find nothing.)
+__device__ __forceinline__ uint32_t quad_list_len(const Workspace& W) { return W.counters[4] + W.counters[11]; }
+__device__ __forceinline__ uint32_t quad_list_at(const Workspace& W, uint64_t li) {
+    const uint32_t ns = W.counters[4];
+    return li < ns ? W.exc_quad[li] : W.exc_quad[W.cap_exc - 1 - (int64_t)(li - ns)];
+}
+constexpr int QUAD_SHORT_UNITS = 128;
 __device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane, int32_t len) {
     // (a length from k_tiles can be anything up to a tile's window; outside byte-encoder mode the quad list is d_exc_lane_fast's only)
     const bool to_quad = leave && (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && len + T.n_prefix <= QUAD_UNITS;
-    const unsigned long long bq = __ballot(to_quad), bw = __ballot(leave && !to_quad);
-    if (bq | bw) {
-        uint32_t aq = 0, aw = 0;
+    const bool to_short = to_quad && len + T.n_prefix <= QUAD_SHORT_UNITS;
+    const unsigned long long bs = __ballot(to_short), bl = __ballot(to_quad && !to_short), bw = __ballot(leave && !to_quad);
+    if (bs | bl | bw) {
+        uint32_t as = 0, al = 0, aw = 0;
         if (lane == 0) {
-            if (bq) aq = atomicAdd(&W.counters[4], (uint32_t)__popcll(bq));
+            if (bs) as = atomicAdd(&W.counters[4], (uint32_t)__popcll(bs));
+            if (bl) al = atomicAdd(&W.counters[11], (uint32_t)__popcll(bl));
             if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
         }
-        aq = __shfl(aq, 0, 64);
+        as = __shfl(as, 0, 64);
+        al = __shfl(al, 0, 64);
         aw = __shfl(aw, 0, 64);
         const unsigned long long below = (1ull << lane) - 1ull;
-        if (to_quad) W.exc_quad[aq + __popcll(bq & below)] = (uint32_t)idx;
+        if (to_short) W.exc_quad[as + __popcll(bs & below)] = (uint32_t)idx;
+        else if (to_quad) W.exc_quad[W.cap_exc - 1 - (int64_t)(al + __popcll(bl & below))] = (uint32_t)idx;
         else if (leave) W.exc_wave[aw + __popcll(bw & below)] = (uint32_t)idx;
     }
 }
@@ -1792,7 +1806,7 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
     const int lane = threadIdx.x & 63;
     uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + (lane % LANES) * ROW;
     constexpr uint32_t HI = 0xFFFF0000u;
-    const uint32_t n_exc = NW == 1 ? W.counters[0] : W.counters[4];  // records, or entries of the quad list
+    const uint32_t n_exc = NW == 1 ? W.counters[0] : quad_list_len(W);  // records, or entries of the quad list (both halves)
     // 64 words at a time: the first lot by block index, further ones from a device cursor (counters[3]): words differ in
     // their number of merges, and a fixed share per wavefront left the last ones running alone
     for (uint32_t round = 0;; round++) {
@@ -1806,7 +1820,7 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
         const uint64_t at = base + lane;
         bool have = lane < LANES && at < n_exc && (NW > 1 || (int64_t)at < W.cap_exc);
         uint64_t idx = at;  // the word's exception record
-        if (NW > 1 && have) idx = W.exc_quad[at];
+        if (NW > 1 && have) idx = quad_list_at(W, at);
         ExcRec rec{};
         if (have) rec = W.exc[idx];
         if (NW == 1) {
@@ -1838,8 +1852,8 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
         if (have) {
             const int64_t ws = rec.ws;
             const int nb = rec.len;
-            const int64_t d = doc_of(A, W, ws, rec.tile);
-            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
+            const int64_t d = T.has_prefix ? doc_of(A, W, ws, rec.tile) : 0;  // (needed for the prefix and its room in exc_tok only)
+            const bool docfirst = T.has_prefix && word_is_first(A, ws, A.offsets[d]);
             const bool with_prefix = T.has_prefix && docfirst;
             const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
@@ -1956,9 +1970,24 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
             int k = na;
 #pragma unroll
             for (int j = 0; j < NW; j++)
-                for (uint64_t c = live.w[j]; c; c &= c - 1) {
-                    const uint32_t sy = U[64 * j + __builtin_ctzll(c)] & 0xFFFFu;
-                    out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
+                for (uint64_t c = live.w[j]; c;) {  // eight ids per step, as in d_exc_group_fast
+                    int pos[8];
+                    bool ok[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        ok[i] = c != 0;
+                        pos[i] = ok[i] ? __builtin_ctzll(c) : 0;
+                        c &= c - 1;
+                    }
+                    uint32_t sy[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sy[i] = U[64 * j + pos[i]] & 0xFFFFu;
+                    int32_t id[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) id[i] = sym_to_id(T, sy[i] == 0xFFFFu ? SYM_UNK : sy[i]);
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (ok[i]) { out[k] = id[i]; k++; }
                 }
             rec.cnt = (uint32_t)k;
             rec.tok_base = gbase;
@@ -2003,9 +2032,9 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
     const int lane = threadIdx.x & 63, sub = lane % LPW, w = lane / LPW;
     uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + w * ROW;
     constexpr uint32_t HI = 0xFFFF0000u;
-    const uint32_t n_exc = W.counters[4];  // entries of the quad list
+    const uint32_t n_exc = W.counters[NW == 2 ? 4 : 11];  // entries of my half of the quad list (medium_leave)
 #if HUTK_LAB_EXC_STAMPS
-    long long st_acc[4] = {0, 0, 0, 0}, st_trips = 0, st_lots = 0;
+    long long st_acc[4] = {0, 0, 0, 0}, st_trips = 0, st_lots = 0, st_set[4] = {0, 0, 0, 0};
     const long long st_begin = clock64();
 #endif
     for (uint32_t round = 0;; round++) {
@@ -2014,15 +2043,22 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
             if (lane == 0) lot = vgrid + atomicAdd(&W.counters[NW == 2 ? 8 : 9], 1u);
             lot = (uint32_t)__shfl((int)lot, 0, 64);
         }
+#if HUTK_LAB_EXC_STAMPS
+        const long long sl0 = clock64();
+#endif
         const uint64_t base = (uint64_t)lot * WPW;
         if (base >= n_exc) break;
         const uint64_t at = base + w;
         bool have = at < n_exc;  // (the same for a group's lanes, as everything below that does not mention sub)
         uint64_t idx = 0;
-        if (have) idx = W.exc_quad[at];
+        if (have) idx = NW == 2 ? W.exc_quad[at] : W.exc_quad[W.cap_exc - 1 - (int64_t)at];
         ExcRec rec{};
         if (have) rec = W.exc[idx];
         const uint32_t rec_tile = rec.tile;  // (the record itself does not stay in registers over the trips)
+#if HUTK_LAB_EXC_STAMPS
+        asm volatile("" :: "v"(rec_tile));
+        const long long sl1 = clock64();
+#endif
         int64_t gbase = 0;
         int n = 0, na = 0;
         uint64_t lv = 0;       // the lane's share of the liveness bits: units 64 sub .. 64 sub + 63
@@ -2046,34 +2082,65 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
         if (have) {
             const int64_t ws = rec.ws;
             const int nb = rec.len;
-            const int64_t d = doc_of(A, W, ws, rec.tile);
-            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
+            // (the word's document matters for the prefix and its room in exc_tok only: without a prefix, five dependent loads less)
+            const int64_t d = T.has_prefix ? doc_of(A, W, ws, rec.tile) : 0;
+            const bool docfirst = T.has_prefix && word_is_first(A, ws, A.offsets[d]);
             const bool with_prefix = T.has_prefix && docfirst;
             const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
             na = alone ? T.n_prefix_alone : 0;
             gbase = ws * T.unit_scale + (int64_t)W.pad_per_doc * (docfirst ? d : d + 1);
-            if (kp + nb > UNITS || (NW == 4 && kp + nb <= UNITS / 2)) {
-                have = false;  // NW == 2: left to the NW == 4 pass (or to d_exc); NW == 4: the NW == 2 pass took it
+            if (kp + nb > UNITS) {
+                have = false;  // (cannot be: the lists were made with the prefix counted in)
             } else {
                 if (sub == 0)
                     for (int i = 0; i < kp; i++) U[i] = HI | (T.prefix_syms[i] & 0xFFFFu);
                 n = kp;
                 int looked_up = 0;  // units [0, looked_up) still need their pair result from the pair table
                 if (T.is_byte_encoder) {
-                    // eight units per step and lane (d_exc_lane_fast: sixteen -- and 40 more registers), the steps dealt round the group
+                    // eight units per step and lane, the steps dealt round the group, two steps at a time: their bytes as three
+                    // unaligned dwords each (the ninth byte is the next unit's: its pair), then their sixteen byte-pair entries
+                    // in flight together -- two round trips per sixteen of the lane's units
                     const uint8_t* wb = A.bytes + ws;
                     const uint32_t* bp = reinterpret_cast<const uint32_t*>(T.bytepair);
-                    for (int i0 = 8 * sub; i0 < nb; i0 += 8 * LPW) {
-                        uint32_t b[9];
+                    const bool wide_ok = ws + ((nb + 7) & ~7) + 4 <= A.n_bytes;  // (a dword may reach 11 bytes past a step's first)
+                    for (int i00 = 8 * sub; i00 < nb; i00 += 16 * LPW) {
+                        uint32_t wd[2][3];
 #pragma unroll
-                        for (int j = 0; j < 9; j++) b[j] = wb[min(i0 + j, nb - 1)];  // (clamped: in bounds, no branch)
-                        uint32_t e[8];
+                        for (int h = 0; h < 2; h++) {
+                            const int i0 = i00 + 8 * LPW * h;
+                            if (wide_ok) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) e[j] = bp[b[j] | (b[j + 1] << 8)];
+                                for (int j = 0; j < 3; j++) {
+                                    uint32_t x;
+                                    __builtin_memcpy(&x, wb + min(i0, (nb - 1) & ~7) + 4 * j, 4);
+                                    wd[h][j] = x;
+                                }
+                            } else {
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (i0 + j < nb) U[n + i0 + j] = (i0 + j + 1 < nb) ? e[j] : (e[j] | HI);
+                                for (int j = 0; j < 3; j++) {
+                                    uint32_t x = 0;
+                                    for (int q = 0; q < 4; q++) x |= (uint32_t)wb[min(i0 + 4 * j + q, nb - 1)] << (8 * q);
+                                    wd[h][j] = x;
+                                }
+                            }
+                        }
+                        uint32_t e[2][8];
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                const uint32_t b0 = (wd[h][j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                                const uint32_t b1 = (wd[h][(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;
+                                e[h][j] = bp[b0 | (b1 << 8)];
+                            }
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int i0 = i00 + 8 * LPW * h;
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                if (i0 + j < nb) U[n + i0 + j] = (i0 + j + 1 < nb) ? e[h][j] : (e[h][j] | HI);
+                        }
                     }
                     looked_up = n;  // (prefix units in front: their pairs, and the one into the word)
                     n += nb;
@@ -2138,12 +2205,19 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
                 for (int j = 0; j < 4; j++) bm[j] = k == j ? r : bm[j];
             }
         };
+#if HUTK_LAB_EXC_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const long long sl2 = clock64();
+#endif
         if (have) {
             scan_all();
             best = group_min_u32<LPW>(min(min(bm[0], bm[1]), min(bm[2], bm[3])));
         }
 #if HUTK_LAB_EXC_STAMPS
         st_lots++;
+        asm volatile("" :: "v"(best));
+        const long long sl3 = clock64();
+        st_set[0] += sl1 - sl0; st_set[1] += sl2 - sl1; st_set[2] += sl3 - sl2;
 #endif
         // One merge per trip and word
         for (;;) {
@@ -2214,6 +2288,9 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
             }
 #endif
         }
+#if HUTK_LAB_EXC_STAMPS
+        const long long sl4 = clock64();
+#endif
         if (have) {
             int32_t* out = W.exc_tok + gbase;
             if (sub == 0)
@@ -2228,9 +2305,27 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
             }
             const int total = na + __shfl(incl, LPW - 1, LPW);
             int k = na + incl - cnt;
-            for (uint64_t c = lv; c; c &= c - 1) {
-                const uint32_t sy = U[64 * sub + __builtin_ctzll(c)] & 0xFFFFu;
-                out[k++] = sym_to_id(T, sy == 0xFFFFu ? SYM_UNK : sy);
+            // eight ids per step: their symbols' LDS reads together, their sym_id loads together (one by one, each id was a
+            // dependent LDS read and global load: 46 k of a lot's 85 k cycles outside its trips, profiles/r04_exc_group_ab.txt)
+            for (uint64_t c = lv; c;) {
+                int pos[8];
+                bool ok[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    ok[j] = c != 0;
+                    pos[j] = ok[j] ? __builtin_ctzll(c) : 0;
+                    c &= c - 1;  // (0 stays 0)
+                }
+                uint32_t sy[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) sy[j] = U[64 * sub + pos[j]] & 0xFFFFu;
+                int32_t id[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) id[j] = sym_to_id(T, sy[j] == 0xFFFFu ? SYM_UNK : sy[j]);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (ok[j]) out[k + j] = id[j];
+                k += 8;  // (the last step's surplus is not stored)
             }
             if (sub == 0) {
                 W.exc[idx].cnt = (uint32_t)total;
@@ -2238,11 +2333,15 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
                 atomicAdd(&W.tile_count[rec_tile], (uint32_t)total);
             }
         }
+#if HUTK_LAB_EXC_STAMPS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        st_set[3] += clock64() - sl4;
+#endif
     }
 #if HUTK_LAB_EXC_STAMPS
     if (W.prof && lane == 0 && vblock < (uint32_t)A.n_tiles) {
         long long* o = W.prof + (size_t)vblock * 10;
-        if (NW == 2) { o[0] = clock64() - st_begin; o[1] = st_acc[0]; o[2] = st_acc[1]; o[3] = st_acc[2]; o[4] = st_trips; o[5] = st_lots; }
+        if (NW == 2) { o[0] = clock64() - st_begin; o[1] = st_acc[0]; o[2] = st_acc[1]; o[3] = st_acc[2]; o[4] = st_trips; o[5] = st_lots; o[6] = st_set[0]; o[7] = st_set[1]; o[8] = st_set[2]; o[9] = st_set[3]; }
     }
 #endif
 }
@@ -2464,22 +2563,22 @@ __device__ __forceinline__ void d_exc_quad(const DevTables& T, const BatchArgs& 
     const int lane = threadIdx.x & 63, g = lane >> 4, l = lane & 15, gl0 = lane & 48;  // group, lane in group, its lane 0
     uint32_t* Sg = Sq + g * QUAD_UNITS;
     uint32_t* Mg = Mq + g * QUAD_UNITS;
-    const uint32_t n_list = W.counters[4];
+    const uint32_t n_list = quad_list_len(W);
     for (uint32_t base = vblock * 4; base < n_list; base += vgrid * 4) {
         const uint32_t li = base + g;
         bool have = li < n_list;
         uint32_t idx = 0;
         ExcRec rec{};
         if (have) {
-            idx = W.exc_quad[li];
+            idx = quad_list_at(W, li);
             rec = W.exc[idx];
         }
         int n = 0, na = 0;
         int64_t gbase = 0;
         if (have) {
             const int64_t ws = rec.ws;
-            const int64_t d = doc_of(A, W, ws, rec.tile);
-            const bool docfirst = word_is_first(A, ws, A.offsets[d]);
+            const int64_t d = T.has_prefix ? doc_of(A, W, ws, rec.tile) : 0;  // (needed for the prefix and its room in exc_tok only)
+            const bool docfirst = T.has_prefix && word_is_first(A, ws, A.offsets[d]);
             const bool with_prefix = T.has_prefix && docfirst;
             const bool alone = with_prefix && doc_begins_with_space(A, ws);
             const int kp = (with_prefix && !alone) ? T.n_prefix : 0;
@@ -2694,17 +2793,41 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
     uint32_t* const lw = L.lw;
     const int lane = threadIdx.x;
     const uint32_t n_tiles_exc = W.counters[1];
-    const uint32_t sub = vblock % ENDS_SHARE;
+    // The two lists' places are claimed once per WAVEFRONT, not per tile: the entries of its tiles wait in LDS (a tile's
+    // fit behind what is there, or the lists are written out first).  One atomic per tile on the same two words was
+    // ~50 k same-address atomics for 800 k words of 70-120 letters -- at ~12 ns each most of k_exc_a's 0.65 ms.
+    uint32_t nq = 0, nl = 0, nw = 0;  // (the same in every lane; lq holds the short list from its front and the long one from its back)
+    auto flush = [&]() {
+        wave_sync();
+        uint32_t aq = 0, al = 0, aw = 0;
+        if (lane == 0) {
+            if (nq) aq = atomicAdd(&W.counters[4], nq);
+            if (nl) al = atomicAdd(&W.counters[11], nl);
+            if (nw) aw = atomicAdd(&W.counters[5], nw);
+        }
+        aq = __shfl(aq, 0, 64);
+        al = __shfl(al, 0, 64);
+        aw = __shfl(aw, 0, 64);
+        for (uint32_t i = lane; i < nq; i += 64) W.exc_quad[aq + i] = lq[i];
+        for (uint32_t i = lane; i < nl; i += 64) W.exc_quad[W.cap_exc - 1 - (int64_t)(al + i)] = lq[ENDS_LIST - 1 - i];
+        for (uint32_t i = lane; i < nw; i += 64) W.exc_wave[aw + i] = lw[i];
+        wave_sync();
+        nq = nl = nw = 0;
+    };
     for (uint32_t ti = vblock / ENDS_SHARE; ti < n_tiles_exc; ti += vgrid / ENDS_SHARE) {
         const uint32_t tile = W.exc_tiles[ti];
         const uint32_t first = W.tile_exc_first[tile], nexc = W.tile_nexc[tile];
-        uint32_t nq = 0, nw = 0;  // (the same in every lane)
+        if (max(nq + nl, nw) + nexc > (uint32_t)ENDS_LIST) flush();
         EndsWin cw;
-        for (uint32_t e = sub; e < nexc; e += ENDS_SHARE) {
-            const uint32_t idx = first + e;
-            if ((int64_t)idx >= W.cap_exc) break;
+        // the tile's records sixty-four at a time, their lengths read together: only the words of unknown length are walked
+        // (one record after the other, each a dependent load, cost a tile of ten long words ~10 us for the ONE whose end it
+        // could not see: k_exc_a 0.69 ms on 800 k words of 70-120 letters)
+        static_assert(ENDS_SHARE == 1, "one wavefront per tile");
+        for (uint32_t e0 = 0; e0 < nexc; e0 += 64)
+        for (unsigned long long um = __ballot(e0 + lane < nexc && (int64_t)(first + e0 + lane) < W.cap_exc && W.exc[first + e0 + lane].len < 0);
+             um; um &= um - 1) {
+            const uint32_t idx = first + e0 + (uint32_t)__builtin_ctzll(um);
             const ExcRec rec = W.exc[idx];
-            if (rec.len >= 0) continue;  // d_exc_medium's
             const int64_t ws = rec.ws;
             const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
             bool too_large;
@@ -2721,24 +2844,15 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
             }
             const bool pfx_units = T.has_prefix && word_is_first(A, ws, ds) && !doc_begins_with_space(A, ws);
             const bool quad = (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
+            const bool qshort = quad && nb + T.n_prefix <= QUAD_SHORT_UNITS;
             if (lane == 0) {
                 W.exc[idx].len = (int32_t)nb;
-                if (quad) lq[nq] = idx; else lw[nw] = idx;
+                if (qshort) lq[nq] = idx; else if (quad) lq[ENDS_LIST - 1 - nl] = idx; else lw[nw] = idx;
             }
-            if (quad) nq++; else nw++;
+            if (qshort) nq++; else if (quad) nl++; else nw++;
         }
-        wave_sync();
-        uint32_t aq = 0, aw = 0;
-        if (lane == 0) {
-            if (nq) aq = atomicAdd(&W.counters[4], nq);
-            if (nw) aw = atomicAdd(&W.counters[5], nw);
-        }
-        aq = __shfl(aq, 0, 64);
-        aw = __shfl(aw, 0, 64);
-        for (uint32_t i = lane; i < nq; i += 64) W.exc_quad[aq + i] = lq[i];
-        for (uint32_t i = lane; i < nw; i += 64) W.exc_wave[aw + i] = lw[i];
-        wave_sync();
     }
+    if (nq | nl | nw) flush();
 }
 
 // d_exc: the words that need a whole wavefront (k_exc's list; their lengths are known by now): first entry by block
@@ -2760,9 +2874,9 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         const uint32_t idx = W.exc_wave[li];
         ExcRec rec = W.exc[idx];
         const int64_t ws = rec.ws;
-        const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d];
+        const int64_t d = T.has_prefix ? doc_of(A, W, ws, rec.tile) : 0;  // (needed for the prefix and its room in exc_tok only)
         const int64_t nb = rec.len;
-        const bool docfirst = word_is_first(A, ws, ds);
+        const bool docfirst = T.has_prefix && word_is_first(A, ws, A.offsets[d]);
         const bool with_prefix = T.has_prefix && docfirst;
         const bool alone = with_prefix && doc_begins_with_space(A, ws);  // core.c:365-366, 421-446
         const int kp = (with_prefix && !alone) ? T.n_prefix : 0;

@@ -24,9 +24,10 @@ n_tiles = (len(d) + tb - 1) // tb
 raw = np.zeros((n_tiles, 10), dtype=np.int64)
 assert L.hutk_debug_profile_raw(ctx._h, n_tiles, raw.ctypes.data) == 0
 g = int(os.environ.get("EXB_QUAD", "5120"))
-r = raw[:g, :6].astype(np.float64)
+r = raw[:g, :10].astype(np.float64)
 r = r[r[:, 4] > 0]
 tr = r[:, 4].sum()
 print(f"words {lo}-{hi}: {len(r)} wavefronts with trips; per wavefront: {r[:,0].mean():.0f} cycles alive, {r[:,5].mean():.1f} lots, {r[:,4].mean():.0f} trips")
 print(f"  per trip: neighbours + issue {r[:,1].sum()/tr:.0f}   row search {r[:,2].sum()/tr:.0f}   resolve + minimum {r[:,3].sum()/tr:.0f}   sum {r[:,1:4].sum()/tr:.0f}")
+print(f"  per lot: cursor + list entry + record {r[:,6].sum()/r[:,5].sum():.0f}   bytes, byte-pair entries, row {r[:,7].sum()/r[:,5].sum():.0f}   first search {r[:,8].sum()/r[:,5].sum():.0f}   output {r[:,9].sum()/r[:,5].sum():.0f}")
 print(f"  outside the trips (set-up, output, cursor): {(r[:,0].sum() - r[:,1:4].sum())/r[:,5].sum():.0f} cycles per lot; trips are {r[:,1:4].sum()/r[:,0].sum()*100:.1f} % of the wavefronts' life")
