@@ -103,7 +103,7 @@ struct hutk_ctx {
     DevBuf<uint32_t> w_exc_sym, w_exc_mrg, w_tile_u32, w_doc_pos, w_counters;
     DevBuf<int64_t> w_tile_i64;
     DevBuf<ExcRec> w_exc;
-    DevBuf<uint32_t> w_exc_quad, w_exc_wave;
+    DevBuf<uint32_t> w_exc_quad, w_exc_mid, w_exc_wave;
 
     // decode direction: tables and workspace
     DevBuf<uint2> d_dec_ent, d_dec_sent;
@@ -349,6 +349,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     const int64_t cap_exc = (c->tab.has_multi ? n_bytes : n_bytes / LANE_MAX_UNITS) + n_docs + n_tiles + 64;
     HIP_TRY(c->w_exc.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_quad.reserve((size_t)cap_exc));
+    HIP_TRY(c->w_exc_mid.reserve((size_t)cap_exc));
     HIP_TRY(c->w_exc_wave.reserve((size_t)cap_exc));
     W.run = c->w_run.p;
     W.exc_tok = c->w_exc_tok.p;
@@ -370,6 +371,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.doc_tile_pos = c->w_doc_pos.p;
     W.exc = c->w_exc.p;
     W.exc_quad = c->w_exc_quad.p;
+    W.exc_mid = c->w_exc_mid.p;
     W.exc_wave = c->w_exc_wave.p;
     W.counters = c->w_counters.p;
     W.cap_exc = cap_exc;
@@ -397,7 +399,7 @@ void destroy(hutk_ctx* c) {
         c->d_word_tab.release(); c->w_wbits.release(); c->w_gbits.release(); c->w_fbits.release(); c->w_abits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
         c->w_tile_u32.release(); c->w_doc_pos.release(); c->w_counters.release(); c->w_tile_i64.release();
-        c->w_exc.release(); c->w_exc_quad.release(); c->w_exc_wave.release();
+        c->w_exc.release(); c->w_exc_quad.release(); c->w_exc_mid.release(); c->w_exc_wave.release();
         c->d_dec_ent.release(); c->d_dec_sent.release(); c->d_dec_blob.release(); c->dw_first.release();
         c->dw_state.release(); c->dw_tfd.release(); c->ds_ids.release(); c->ds_status.release();
         c->ds_offs.release(); c->ds_oo.release(); c->ds_bytes.release(); c->w_err.release();

@@ -111,9 +111,10 @@ struct Workspace {
     int64_t n_scan_blocks;
     uint32_t* doc_tile_pos;    // [n_docs + 1] ids the owning tile emits before the document start
     ExcRec* exc;               // [cap_exc]
-    uint32_t* exc_quad;        // [cap_exc] exception words of at most 256 units for d_exc_quad (count: counters[4])
+    uint32_t* exc_quad;        // [cap_exc] exception words of at most 128 units from the front (count: counters[4]), of 129..256 from the back (counters[11]): d_exc_group_fast<2>, <4> (or d_exc_quad, both as one list)
+    uint32_t* exc_mid;         // [cap_exc] ... of 257..512 units from the front (counters[12]), of 513..1024 from the back (counters[13]): d_exc_group_fast<8>, <16>
     uint32_t* exc_wave;        // [cap_exc] ... the rest, one wavefront each in d_exc (count: counters[5])
-    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] d_exc's work cursor, [3] d_exc_lane_fast<1>'s (k_exc_a), [8] d_exc_lane_fast<4>'s (k_exc_b), [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
+    uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] d_exc's work cursor, [3] d_exc_lane_fast<1>'s (k_exc_a), [8] [9] [14] [15] d_exc_group_fast<2>'s .. <16>'s (k_exc_b), [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
     uint32_t* noreal_bits;     // [n_tiles / 32 + 1] bit t: tile t holds no word start of the reference's own (k_cut)
     uint32_t* tile_lastreal;   // [n_tiles] position of the tile's last such start | ids before it << 16 (written when none follows in the halo)

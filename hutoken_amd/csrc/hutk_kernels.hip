@@ -1725,25 +1725,35 @@ __device__ __forceinline__ uint32_t quad_list_at(const Workspace& W, uint64_t li
     return li < ns ? W.exc_quad[li] : W.exc_quad[W.cap_exc - 1 - (int64_t)(li - ns)];
 }
 constexpr int QUAD_SHORT_UNITS = 128;
+constexpr int GROUP_UNITS = 1024;  // longest word of d_exc_group_fast (16 lanes per word)
+// the list of a word of `units` units (the prefix counted in, whether or not the word gets it): 0 / 1 the quad list's halves,
+// 2 / 3 exc_mid's (d_exc_group_fast<8>, <16>: 16-bit symbols with rank == symbol order only), 4 d_exc's
+__device__ __forceinline__ int exc_list_of(const DevTables& T, int64_t units) {
+    const bool quad_ok = (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi;
+    const bool group_ok = HUTK_LAB_EXC_GROUP && T.sym16 && T.rank_is_sym && !T.has_multi;
+    return quad_ok && units <= QUAD_SHORT_UNITS ? 0 : quad_ok && units <= QUAD_UNITS ? 1
+         : group_ok && units <= GROUP_UNITS / 2 ? 2 : group_ok && units <= GROUP_UNITS ? 3 : 4;
+}
+__device__ __forceinline__ uint32_t* exc_list_slot(const Workspace& W, int list, uint32_t k) {  // entry k of list 0 .. 4
+    return list == 0 ? W.exc_quad + k : list == 1 ? W.exc_quad + (W.cap_exc - 1 - (int64_t)k)
+         : list == 2 ? W.exc_mid + k : list == 3 ? W.exc_mid + (W.cap_exc - 1 - (int64_t)k) : W.exc_wave + k;
+}
+__device__ __forceinline__ uint32_t* exc_list_count(const Workspace& W, int list) {
+    return W.counters + (list == 0 ? 4 : list == 1 ? 11 : list == 2 ? 12 : list == 3 ? 13 : 5);
+}
 __device__ __forceinline__ void medium_leave(const DevTables& T, const Workspace& W, bool leave, uint64_t idx, int lane, int32_t len) {
     // (a length from k_tiles can be anything up to a tile's window; outside byte-encoder mode the quad list is d_exc_lane_fast's only)
-    const bool to_quad = leave && (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && len + T.n_prefix <= QUAD_UNITS;
-    const bool to_short = to_quad && len + T.n_prefix <= QUAD_SHORT_UNITS;
-    const unsigned long long bs = __ballot(to_short), bl = __ballot(to_quad && !to_short), bw = __ballot(leave && !to_quad);
-    if (bs | bl | bw) {
-        uint32_t as = 0, al = 0, aw = 0;
-        if (lane == 0) {
-            if (bs) as = atomicAdd(&W.counters[4], (uint32_t)__popcll(bs));
-            if (bl) al = atomicAdd(&W.counters[11], (uint32_t)__popcll(bl));
-            if (bw) aw = atomicAdd(&W.counters[5], (uint32_t)__popcll(bw));
+    const int list = leave ? exc_list_of(T, (int64_t)len + T.n_prefix) : -1;
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int l = 0; l < 5; l++) {  // one atomic per wavefront and list
+        const unsigned long long b = __ballot(list == l);
+        if (b) {
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(exc_list_count(W, l), (uint32_t)__popcll(b));
+            at = __shfl(at, 0, 64);
+            if (list == l) *exc_list_slot(W, l, at + __popcll(b & below)) = (uint32_t)idx;
         }
-        as = __shfl(as, 0, 64);
-        al = __shfl(al, 0, 64);
-        aw = __shfl(aw, 0, 64);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (to_short) W.exc_quad[as + __popcll(bs & below)] = (uint32_t)idx;
-        else if (to_quad) W.exc_quad[W.cap_exc - 1 - (int64_t)(al + __popcll(bl & below))] = (uint32_t)idx;
-        else if (leave) W.exc_wave[aw + __popcll(bw & below)] = (uint32_t)idx;
     }
 }
 
@@ -2012,27 +2022,31 @@ __device__ __forceinline__ void d_exc_lane_fast(const DevTables& T, const BatchA
 // wavefronts per SIMD the kernel is bound by the instructions it issues, not by a trip's latency (k_exc_b with half its
 // wavefronts took the same time, profiles/r04_exc_group_ab.txt).
 template <int LPW>
-__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {  // minimum over each group of LPW (2, 4) lanes, in every lane
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {  // minimum over each group of LPW (2 .. 16) lanes, in every lane
     v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
-    if (LPW == 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    if (LPW >= 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    if (LPW >= 8) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    if (LPW >= 16) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, 0x140, 0xf, 0xf, false)); // row_mirror
     return v;
 }
 template <int LPW>
 __device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false));
-    if (LPW == 4) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    if (LPW >= 4) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false));
+    if (LPW >= 8) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false));
+    if (LPW >= 16) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false));
     return v;
 }
 template <int NW>
 __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
                                                  uint32_t vgrid, uint8_t* lds) {
     constexpr int LPW = NW, UNITS = 64 * NW, ROW = UNITS + 4, WPW = 64 / LPW;
-    static_assert(NW == 2 || NW == 4, "groups of two or four lanes (quad_perm)");
-    static_assert(UNITS <= QUAD_UNITS, "the quad list holds words of up to QUAD_UNITS units");
+    static_assert(NW == 2 || NW == 4 || NW == 8 || NW == 16, "groups within a DPP row");
+    static_assert(UNITS <= GROUP_UNITS, "the lists hold words of up to GROUP_UNITS units");
     const int lane = threadIdx.x & 63, sub = lane % LPW, w = lane / LPW;
     uint32_t* const U = reinterpret_cast<uint32_t*>(lds) + w * ROW;
     constexpr uint32_t HI = 0xFFFF0000u;
-    const uint32_t n_exc = W.counters[NW == 2 ? 4 : 11];  // entries of my half of the quad list (medium_leave)
+    const uint32_t n_exc = W.counters[NW == 2 ? 4 : NW == 4 ? 11 : NW == 8 ? 12 : 13];  // entries of my list (medium_leave)
 #if HUTK_LAB_EXC_STAMPS
     long long st_acc[4] = {0, 0, 0, 0}, st_trips = 0, st_lots = 0, st_set[4] = {0, 0, 0, 0};
     const long long st_begin = clock64();
@@ -2040,7 +2054,7 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
     for (uint32_t round = 0;; round++) {
         uint32_t lot = vblock;
         if (round) {
-            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[NW == 2 ? 8 : 9], 1u);
+            if (lane == 0) lot = vgrid + atomicAdd(&W.counters[NW == 2 ? 8 : NW == 4 ? 9 : NW == 8 ? 14 : 15], 1u);
             lot = (uint32_t)__shfl((int)lot, 0, 64);
         }
 #if HUTK_LAB_EXC_STAMPS
@@ -2051,7 +2065,7 @@ __device__ __forceinline__ void d_exc_group_fast(const DevTables& T, const Batch
         const uint64_t at = base + w;
         bool have = at < n_exc;  // (the same for a group's lanes, as everything below that does not mention sub)
         uint64_t idx = 0;
-        if (have) idx = NW == 2 ? W.exc_quad[at] : W.exc_quad[W.cap_exc - 1 - (int64_t)at];
+        if (have) idx = NW == 2 ? W.exc_quad[at] : NW == 4 ? W.exc_quad[W.cap_exc - 1 - (int64_t)at] : NW == 8 ? W.exc_mid[at] : W.exc_mid[W.cap_exc - 1 - (int64_t)at];
         ExcRec rec{};
         if (have) rec = W.exc[idx];
         const uint32_t rec_tile = rec.tile;  // (the record itself does not stay in registers over the trips)
@@ -2780,7 +2794,7 @@ struct EndsLds {
     __attribute__((aligned(16))) uint8_t sb[EXC_WIN];
     uint8_t scode[EXC_WIN];
     uint32_t docm[EXC_WIN / 32 + 1];
-    uint32_t lq[ENDS_LIST], lw[ENDS_LIST];
+    uint32_t lq[ENDS_LIST], lm[ENDS_LIST], lw[ENDS_LIST];
 };
 constexpr uint32_t ENDS_SHARE = 1;  // wavefronts that share the words of one tile (one: the splitter's window is reused from word to word)
 __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
@@ -2790,34 +2804,35 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
     uint8_t* const scode = L.scode;
     uint32_t* const docm = L.docm;
     uint32_t* const lq = L.lq;
+    uint32_t* const lm = L.lm;
     uint32_t* const lw = L.lw;
     const int lane = threadIdx.x;
     const uint32_t n_tiles_exc = W.counters[1];
     // The two lists' places are claimed once per WAVEFRONT, not per tile: the entries of its tiles wait in LDS (a tile's
     // fit behind what is there, or the lists are written out first).  One atomic per tile on the same two words was
     // ~50 k same-address atomics for 800 k words of 70-120 letters -- at ~12 ns each most of k_exc_a's 0.65 ms.
-    uint32_t nq = 0, nl = 0, nw = 0;  // (the same in every lane; lq holds the short list from its front and the long one from its back)
+    // (lq: lists 0 and 1 from its two ends, lm: lists 2 and 3, lw: d_exc's -- exc_list_of)
+    uint32_t nl[5] = {0, 0, 0, 0, 0};  // (the same in every lane)
+    auto lds_slot = [&](int list, uint32_t k) -> uint32_t* {
+        return list == 0 ? lq + k : list == 1 ? lq + (ENDS_LIST - 1 - k) : list == 2 ? lm + k : list == 3 ? lm + (ENDS_LIST - 1 - k) : lw + k;
+    };
     auto flush = [&]() {
         wave_sync();
-        uint32_t aq = 0, al = 0, aw = 0;
-        if (lane == 0) {
-            if (nq) aq = atomicAdd(&W.counters[4], nq);
-            if (nl) al = atomicAdd(&W.counters[11], nl);
-            if (nw) aw = atomicAdd(&W.counters[5], nw);
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+            if (nl[l] == 0) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(exc_list_count(W, l), nl[l]);
+            at = __shfl(at, 0, 64);
+            for (uint32_t i = lane; i < nl[l]; i += 64) *exc_list_slot(W, l, at + i) = *lds_slot(l, i);
+            nl[l] = 0;
         }
-        aq = __shfl(aq, 0, 64);
-        al = __shfl(al, 0, 64);
-        aw = __shfl(aw, 0, 64);
-        for (uint32_t i = lane; i < nq; i += 64) W.exc_quad[aq + i] = lq[i];
-        for (uint32_t i = lane; i < nl; i += 64) W.exc_quad[W.cap_exc - 1 - (int64_t)(al + i)] = lq[ENDS_LIST - 1 - i];
-        for (uint32_t i = lane; i < nw; i += 64) W.exc_wave[aw + i] = lw[i];
         wave_sync();
-        nq = nl = nw = 0;
     };
     for (uint32_t ti = vblock / ENDS_SHARE; ti < n_tiles_exc; ti += vgrid / ENDS_SHARE) {
         const uint32_t tile = W.exc_tiles[ti];
         const uint32_t first = W.tile_exc_first[tile], nexc = W.tile_nexc[tile];
-        if (max(nq + nl, nw) + nexc > (uint32_t)ENDS_LIST) flush();
+        if (max(max(nl[0] + nl[1], nl[2] + nl[3]), nl[4]) + nexc > (uint32_t)ENDS_LIST) flush();
         EndsWin cw;
         // the tile's records sixty-four at a time, their lengths read together: only the words of unknown length are walked
         // (one record after the other, each a dependent load, cost a tile of ten long words ~10 us for the ONE whose end it
@@ -2842,17 +2857,17 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
                 }
                 continue;
             }
-            const bool pfx_units = T.has_prefix && word_is_first(A, ws, ds) && !doc_begins_with_space(A, ws);
-            const bool quad = (T.is_byte_encoder || T.sym16) && T.rank_is_sym && !T.has_multi && nb + (pfx_units ? T.n_prefix : 0) <= QUAD_UNITS;
-            const bool qshort = quad && nb + T.n_prefix <= QUAD_SHORT_UNITS;
+            // (the list by the length with the prefix, whether or not this word gets it: d_exc_group_fast<NW> takes its list whole)
+            const int list = exc_list_of(T, nb + T.n_prefix);
             if (lane == 0) {
                 W.exc[idx].len = (int32_t)nb;
-                if (qshort) lq[nq] = idx; else if (quad) lq[ENDS_LIST - 1 - nl] = idx; else lw[nw] = idx;
+                *lds_slot(list, nl[list == 0 ? 0 : list == 1 ? 1 : list == 2 ? 2 : list == 3 ? 3 : 4]) = idx;
             }
-            if (qshort) nq++; else if (quad) nl++; else nw++;
+#pragma unroll
+            for (int l = 0; l < 5; l++) nl[l] += list == l;
         }
     }
-    if (nq | nl | nw) flush();
+    if (nl[0] | nl[1] | nl[2] | nl[3] | nl[4]) flush();
 }
 
 // d_exc: the words that need a whole wavefront (k_exc's list; their lengths are known by now): first entry by block
@@ -3040,7 +3055,7 @@ __global__ __launch_bounds__(64) void k_exc_a(DevTables T, BatchArgs A, Workspac
 // FAST: 16-bit symbols with rank == symbol order: the quad list goes to d_exc_lane_fast (one lane per word: first the words
 // of up to 128 units, then the longer ones) instead of d_exc_quad
 #if HUTK_LAB_EXC_GROUP
-constexpr size_t LANE_FAST_LDS = cmax(32 * (128 + 4) * 4, 16 * (256 + 4) * 4);  // d_exc_group_fast: 32 / 16 rows
+constexpr size_t LANE_FAST_LDS = cmax(32 * (128 + 4) * 4, 16 * (256 + 4) * 4);  // d_exc_group_fast: 32 / 16 / 8 / 4 rows (the first the largest)
 #else
 constexpr size_t LANE_FAST_LDS = cmax(16 * (128 + 4) * 4, 8 * (256 + 4) * 4);
 #endif
@@ -3066,6 +3081,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HUTK_EXB_EU
             d_exc_group_fast<2>(T, A, W, blockIdx.x, QWGS, lds);
             wave_sync();
             d_exc_group_fast<4>(T, A, W, blockIdx.x, QWGS, lds);
+            wave_sync();
+            d_exc_group_fast<8>(T, A, W, blockIdx.x, QWGS, lds);
+            wave_sync();
+            d_exc_group_fast<16>(T, A, W, blockIdx.x, QWGS, lds);
 #else
             d_exc_lane_fast<2, 16>(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * LANE_FAST_LDS);
             wave_sync();
@@ -3506,6 +3525,10 @@ __global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Wor
             d_exc_group_fast<2>(T, A, W, 0, 1, lds);
             stage_done();
             d_exc_group_fast<4>(T, A, W, 0, 1, lds);
+            stage_done();
+            d_exc_group_fast<8>(T, A, W, 0, 1, lds);
+            stage_done();
+            d_exc_group_fast<16>(T, A, W, 0, 1, lds);
 #else
             d_exc_lane_fast<2, 16>(T, A, W, 0, 1, lds);
             stage_done();

@@ -149,14 +149,15 @@ def test_giant_words(vg_files, oracle_mod):
         assert ids_g.tolist() == list(want)
 
 
-def test_words_of_65_to_256_units(vg_files, vl_files, small_byte, oracle_mod):
-    """d_exc_group_fast: two / four lanes per word, 32 / 16 words per wavefront, block minima in registers.  Every length
-    from 65 to 256 units, enough words of each kind to fill wavefronts and to leave some half empty; words that merge
-    into long tokens (live units far apart: the lane that owns two changed blocks searches all of its blocks); the
-    prefix units of a character vocabulary in front."""
+def test_words_of_65_to_1024_units(vg_files, vl_files, small_byte, oracle_mod):
+    """d_exc_group_fast: two .. sixteen lanes per word, 32 .. 4 words per wavefront, block minima in registers.  Every
+    length from 65 to 256 units and those around the lists' limits (128, 256, 512, 1024), enough words of each kind to
+    fill wavefronts and to leave some half empty; words that merge into long tokens (live units far apart: the lane
+    that owns two changed blocks searches all of its blocks); the prefix units of a character vocabulary in front."""
     from hutoken_amd import synth
     rng = random.Random(65256)
-    letters = [bytes(rng.choice(b"etaoinshrdlucmfw") for _ in range(n)) for n in range(60, 262)] * 2
+    lengths = list(range(60, 262)) * 2 + list(range(505, 520)) + list(range(1015, 1030)) + [rng.randrange(257, 1025) for _ in range(60)]
+    letters = [bytes(rng.choice(b"etaoinshrdlucmfw") for _ in range(n)) for n in lengths]
     rng.shuffle(letters)
     # words of the corpus glued together: they merge back into their tokens, a dozen bytes and more each
     data, offs = synth.corpus("C3", 400)
@@ -164,11 +165,11 @@ def test_words_of_65_to_256_units(vg_files, vl_files, small_byte, oracle_mod):
     words = [w for w in words if w.decode("utf-8").isalpha() and max(map(ord, w.decode("utf-8"))) < 0x250]  # (one splitter class)
     glued = []
     for _ in range(300):
-        w, want = b"", rng.randrange(65, 257)
+        w, want = b"", rng.randrange(65, 257) if rng.random() < 0.6 else rng.randrange(257, 1025)
         while len(w) < want:
             w += rng.choice(words)
         glued.append(w[:want].decode("utf-8", "ignore").encode("utf-8"))
-    same = [bytes([c]) * n for c in b"ae" for n in (65, 128, 129, 200, 256)]
+    same = [bytes([c]) * n for c in b"ae" for n in (65, 128, 129, 200, 256, 257, 512, 513, 1024, 1025)]
     docs = [b" ".join(letters[i:i + 7]) for i in range(0, len(letters), 7)]
     docs += [b" ".join(glued[i:i + 5]) for i in range(0, len(glued), 5)]
     docs += [b"x " + w + b" y" for w in same] + letters[:40] + glued[:40]
