@@ -9,7 +9,7 @@ mkdir -p "$OUT"; export TMPDIR=/tmp; cd "$ROOT"
 : > "$OUT.txt"
 for w in "$@"; do
   n=$(echo $w | tr " " _)
-  rocprofv3 --kernel-trace --output-format csv -d "$OUT/$n" -- python3 tools/kernel_times.py words $w > "$OUT/$n.log" 2>&1 || echo "failed: $w"
+  rocprofv3 --kernel-trace --output-format csv -d "$OUT/$n" -- python3 tools/kernel_times.py $( [[ "$w" == [0-9]* ]] && echo words ) $w > "$OUT/$n.log" 2>&1 || echo "failed: $w"
   python3 - "$OUT/$n" "$w" >> "$OUT.txt" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
@@ -17,7 +17,7 @@ d = collections.OrderedDict()
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 for r in rows:
     d.setdefault(r["Kernel_Name"].split("(")[0][-40:], []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-print("== words", sys.argv[2], "(us, last batch)")
+print("==", sys.argv[2], "(us, last batch)")
 tot = 0
 for k, v in d.items():
     if "k_" in k and "hutk" in k:

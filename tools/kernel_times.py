@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Per-kernel GPU time of one device-resident batch of a named workload (run under rocprofv3 --kernel-trace --stats):
-  kernel_times.py C3 200000 | kernel_times.py words 70 120 [docs] | kernel_times.py cjk [docs]"""
+  kernel_times.py C3 200000 | kernel_times.py words 70 120 [docs] | kernel_times.py cjk [docs] (HUTK_NO_SEAM=1: every paragraph one word) | kernel_times.py cjktext [docs] (vocab VC)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hutoken_amd import _capi, data, synth
 
-vp, sp, kw = data.vocab_files("VG")
+vp, sp, kw = data.vocab_files("VC" if sys.argv[1] == "cjktext" else "VG")
 ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
 if sys.argv[1] == "words":
     d, o = synth.random_words(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 100000, 8)
+elif sys.argv[1] == "cjktext":
+    d, o = synth.cjk_text(int(sys.argv[2]) if len(sys.argv) > 2 else 20000)
 elif sys.argv[1] == "cjk":
     d, o = synth.cjk_paragraphs(int(sys.argv[2]) if len(sys.argv) > 2 else 50000)
 else:
