@@ -1419,7 +1419,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 // Cooperative merge of n symbols held in Sa (pairs in Ma) by one wavefront.
 // Dense arrays: a merge removes element p+1 by shifting the tail left.
 template <class Arr>
-__device__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int lane) {
+__device__ __forceinline__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, int64_t n, int lane) {
     for (int64_t i = lane; i < n; i += 64)
         Ma.set(i, (i + 1 < n) ? pair_lookup(T, Sa.get(i), Sa.get(i + 1)) : SYM_NONE);
     wave_wg_sync();
@@ -1481,7 +1481,7 @@ constexpr uint32_t UNIT_DEAD = 0xFFFFFFFEu;
 #endif
 constexpr int64_t EXC_SHIFT_MAX = HUTK_EXC_SHIFT_MAX;  // longest word in LDS that d_exc merges by shifting (bpe_wave)
 template <class Arr>
-__device__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1r, uint32_t* L1p, int64_t n,
+__device__ __forceinline__ int64_t bpe_wave_big(const DevTables& T, Arr Sg, Arr Mg, uint32_t* L1r, uint32_t* L1p, int64_t n,
                                 int lane) {
     const int64_t CH = (((n + EXC_LDS_UNITS - 1) / EXC_LDS_UNITS) + 63) & ~(int64_t)63;  // units per chunk
     const int NC = (int)((n + CH - 1) / CH);                                               // <= 1024
@@ -1589,8 +1589,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // are searched again without the entries that are about to change, which are folded in when the loads are back.  No workgroup
 // barrier: one wavefront, LDS in program order.
 constexpr uint32_t FL_NONE = 0x7FFu, FL_SYM = 0xFFFFFu, FL_DEAD = 0x80000000u;
-static_assert(EXC_LDS_UNITS <= 1024, "ten bits of position in the key, eleven in the links");
-__device__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml, uint32_t* l1, int n, int lane) {
+constexpr int FAST_LDS_UNITS = 2046;  // eleven bits of position in the key and in the links, 0x7FF means "none" (d_exc<2048>)
+__device__ __forceinline__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml, uint32_t* l1, int n, int lane) {
     constexpr uint32_t NOKEY = 0xFFFFFFFFu;
     const int NC = (n + 63) >> 6;
     // links and the pair results of neighbours, every unit at once
@@ -1612,7 +1612,7 @@ __device__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml,
         uint32_t k = NOKEY;
         if ((int)i < n && i != skip_a && i != skip_b) {
             const uint32_t m = Ml[i] & FL_SYM;
-            if (m != PAIR_ABSENT) k = (m << 10) | i;
+            if (m != PAIR_ABSENT) k = (m << 11) | i;
         }
         return wave_min_u32(k);
     };
@@ -1625,7 +1625,7 @@ __device__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml,
     for (;;) {
         const uint32_t best = wave_min_u32(lane < NC ? l1[lane] : NOKEY);
         if (best == NOKEY) break;
-        const uint32_t p = best & 1023u, merged = best >> 10;
+        const uint32_t p = best & 2047u, merged = best >> 11;
         const uint32_t sp = Sl[p], mp = Ml[p];
         const uint32_t q = (sp >> 20) & FL_NONE, p0 = (mp >> 20) & FL_NONE;  // the unit the merge consumes (there is one), the unit in front (or none)
         const uint32_t sq = Sl[q];
@@ -1658,8 +1658,8 @@ __device__ int64_t bpe_wave_fast(const DevTables& T, uint32_t* Sl, uint32_t* Ml,
         const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)lk, 0), ml = (uint32_t)__builtin_amdgcn_readlane((int)lk, 1);
         const uint32_t mrf = (q2 != FL_NONE && mr != SYM_NONE) ? mr : PAIR_ABSENT;
         const uint32_t mlf = (p0 != FL_NONE && ml != SYM_NONE) ? ml : PAIR_ABSENT;
-        const uint32_t key_r = mrf != PAIR_ABSENT ? ((mrf << 10) | p) : NOKEY;
-        const uint32_t key_l = mlf != PAIR_ABSENT ? ((mlf << 10) | p0) : NOKEY;
+        const uint32_t key_r = mrf != PAIR_ABSENT ? ((mrf << 11) | p) : NOKEY;
+        const uint32_t key_l = mlf != PAIR_ABSENT ? ((mlf << 11) | p0) : NOKEY;
         kp = min(kp, key_r);
         if (c0 == cp) kp = min(kp, key_l);
         else if (c0 == cq) kq = min(kq, key_l);
@@ -2872,10 +2872,15 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
 
 // d_exc: the words that need a whole wavefront (k_exc's list; their lengths are known by now): first entry by block
 // index, further ones from a device cursor.
+// LU: units of the two LDS arrays -- EXC_LDS_UNITS (1024), or 2048 where the words of up to 1024 units have gone to
+// d_exc_group_fast and the LDS they needed is free (k_exc_b<true>): words of up to 2046 units merge in LDS then, where at
+// 1025 they used to fall to the arrays in HBM (CJK paragraphs of 1025..1200 bytes under a dense vocabulary: most of k_exc_b).
+template <int LU = EXC_LDS_UNITS>
 __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
                                       uint32_t vgrid, uint8_t* lds) {
+    static_assert(LU == EXC_LDS_UNITS || LU == 2048, "bpe_wave_big's chunk arrays are EXC_LDS_UNITS entries of them");
     uint32_t* const Sl = reinterpret_cast<uint32_t*>(lds);
-    uint32_t* const Ml = Sl + EXC_LDS_UNITS;
+    uint32_t* const Ml = Sl + LU;
 
     const int lane = threadIdx.x & 63;  // (k_exc_b runs two of these per workgroup, each wavefront on its own: no s_barrier in here)
     const uint32_t n_list = W.counters[5];
@@ -2925,7 +2930,7 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
             n_units = cnt;
         }
         const int64_t n = n_units + kp;
-        const bool in_lds = n <= EXC_LDS_UNITS;
+        const bool in_lds = n <= (LU == EXC_LDS_UNITS ? EXC_LDS_UNITS : FAST_LDS_UNITS);
         LdsArr Sl_a{Sl}, Ml_a{Ml};
         HbmArr Sg_a{W.exc_sym + gbase}, Mg_a{W.exc_mrg + gbase};
 
@@ -3005,12 +3010,12 @@ __device__ __forceinline__ void d_exc(const DevTables& T, const BatchArgs& A, co
         // In LDS: short words by shifting the tail left after every merge (bpe_wave), longer ones by the same dead-unit
         // marks and per-chunk best keys as the words in HBM (chunks of 64 units, at most 16 of them: a merge costs three
         // chunk rescans instead of a shift of half the word, barriers and all)
-        __shared__ uint32_t s_l1_all[2][2 * (EXC_LDS_UNITS / 64)];
+        __shared__ uint32_t s_l1_all[2][2 * (LU / 64)];
         uint32_t* const s_l1 = s_l1_all[threadIdx.x >> 6];
         const bool fast = in_lds && T.rank_is_sym && n >= 2 && HUTK_LAB_EXC_FAST;  // (rank == symbol order: 32-bit keys, bpe_wave_fast)
         const int64_t left = !in_lds ? bpe_wave_big(T, Sg_a, Mg_a, Sl, Ml, n, lane)
                            : fast ? bpe_wave_fast(T, Sl, Ml, s_l1, (int)n, lane)
-                           : n > EXC_SHIFT_MAX ? bpe_wave_big(T, Sl_a, Ml_a, s_l1, s_l1 + EXC_LDS_UNITS / 64, n, lane)
+                           : n > EXC_SHIFT_MAX ? bpe_wave_big(T, Sl_a, Ml_a, s_l1, s_l1 + LU / 64, n, lane)
                                                : bpe_wave(T, Sl_a, Ml_a, n, lane);
         const int na = alone ? T.n_prefix_alone : 0;
         int32_t* out = W.exc_tok + gbase;
@@ -3059,42 +3064,40 @@ constexpr size_t LANE_FAST_LDS = cmax(32 * (128 + 4) * 4, 16 * (256 + 4) * 4);  
 #else
 constexpr size_t LANE_FAST_LDS = cmax(16 * (128 + 4) * 4, 8 * (256 + 4) * 4);
 #endif
-// Workgroups of TWO wavefronts that never meet: d_exc_group_fast wants 16.5 KB of LDS for ONE wavefront (the second one of
-// its workgroups leaves at once), d_exc and d_exc_quad 8 KB per wavefront -- so a CU holds 9 of the former or 18 of the
-// latter, where one wavefront per workgroup at 16.5 KB would have halved d_exc's (measured: words of 300-900 letters
-// 6.6 -> 4.0 GB/s).  Nothing in these roles is a workgroup barrier (wave_wg_sync).
-constexpr size_t EXB_WAVE_LDS = cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4);  // per wavefront of d_exc_quad / d_exc
-constexpr int EXB_QUAD_WGS = HUTK_LAB_EXC_GROUP ? 2304 : EXB_QUAD / 2;  // (FAST: 9 per CU, the rest of the list by the device cursor)
+// k_exc_b<true> (16-bit symbols, rank == symbol order): 2304 workgroups of ONE wavefront, 16.5 KB of LDS each, nine per
+// CU, all resident: each walks the four lists of d_exc_group_fast and then d_exc's (words beyond 1024 units, in the same
+// LDS: up to 2046 units).  k_exc_b<false> (other vocabularies): workgroups of TWO wavefronts that never meet, 8 KB of LDS
+// each (d_exc_quad, d_exc: 18 per CU) -- nothing in these roles is a workgroup barrier (wave_wg_sync).
+constexpr size_t EXB_WAVE_LDS = cmax(2 * 4 * QUAD_UNITS * 4, 2 * EXC_LDS_UNITS * 4);  // per wavefront of d_exc_quad / d_exc<1024>
+constexpr int EXB_FAST_WGS = 2304;
 #ifndef HUTK_EXB_EU
 #define HUTK_EXB_EU 5
 #endif
 template <bool FAST>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(HUTK_EXB_EU))) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[cmax(2 * EXB_WAVE_LDS, FAST ? (HUTK_LAB_EXC_GROUP ? 1 : 2) * LANE_FAST_LDS : 0)];
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(FAST ? 3 : HUTK_EXB_EU))) void k_exc_b(DevTables T, BatchArgs A, Workspace W) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[FAST ? cmax(HUTK_LAB_EXC_GROUP ? LANE_FAST_LDS : 2 * LANE_FAST_LDS, 2 * 2048 * 4) : 2 * EXB_WAVE_LDS];
     if (W.counters[0] == 0) return;
     const uint32_t wv = threadIdx.x >> 6;
-    constexpr uint32_t QWGS = FAST ? EXB_QUAD_WGS : EXB_QUAD / 2;
-    if (blockIdx.x < QWGS) {
-        if (FAST) {
+    if (FAST) {
 #if HUTK_LAB_EXC_GROUP
-            if (wv) return;
-            d_exc_group_fast<2>(T, A, W, blockIdx.x, QWGS, lds);
-            wave_sync();
-            d_exc_group_fast<4>(T, A, W, blockIdx.x, QWGS, lds);
-            wave_sync();
-            d_exc_group_fast<8>(T, A, W, blockIdx.x, QWGS, lds);
-            wave_sync();
-            d_exc_group_fast<16>(T, A, W, blockIdx.x, QWGS, lds);
+        d_exc_group_fast<2>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
+        wave_sync();
+        d_exc_group_fast<4>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
+        wave_sync();
+        d_exc_group_fast<8>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
+        wave_sync();
+        d_exc_group_fast<16>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
 #else
-            d_exc_lane_fast<2, 16>(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * LANE_FAST_LDS);
-            wave_sync();
-            d_exc_lane_fast<4, 8>(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * LANE_FAST_LDS);
+        d_exc_lane_fast<2, 16>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
+        wave_sync();
+        d_exc_lane_fast<4, 8>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
 #endif
-        } else {
-            d_exc_quad(T, A, W, 2 * blockIdx.x + wv, 2 * QWGS, lds + wv * EXB_WAVE_LDS);
-        }
+        wave_sync();
+        d_exc<2048>(T, A, W, blockIdx.x, EXB_FAST_WGS, lds);
+    } else if (blockIdx.x < (uint32_t)EXB_QUAD / 2) {
+        d_exc_quad(T, A, W, 2 * blockIdx.x + wv, EXB_QUAD, lds + wv * EXB_WAVE_LDS);
     } else {
-        d_exc(T, A, W, 2 * (blockIdx.x - QWGS) + wv, EXB_WAVE, lds + wv * EXB_WAVE_LDS);
+        d_exc<EXC_LDS_UNITS>(T, A, W, 2 * (blockIdx.x - EXB_QUAD / 2) + wv, EXB_WAVE, lds + wv * EXB_WAVE_LDS);
     }
 }
 
@@ -3615,7 +3618,7 @@ void launch_exceptions(const DevTables& t, const BatchArgs& a, const Workspace& 
     // two launches, fixed grids; every wavefront pulls work until its device list runs out
     if (t.sym16) hipLaunchKernelGGL(k_exc_a<uint16_t>, dim3(EXA_MEDIUM16 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM16);
     else hipLaunchKernelGGL(k_exc_a<uint32_t>, dim3(EXA_MEDIUM32 + EXA_ENDS), dim3(64), 0, s, t, a, w, (uint32_t)EXA_MEDIUM32);
-    if (t.sym16 && t.rank_is_sym) hipLaunchKernelGGL(k_exc_b<true>, dim3(EXB_QUAD_WGS + EXB_WAVE / 2), dim3(128), 0, s, t, a, w);
+    if (t.sym16 && t.rank_is_sym) hipLaunchKernelGGL(k_exc_b<true>, dim3(EXB_FAST_WGS), dim3(64), 0, s, t, a, w);
     else hipLaunchKernelGGL(k_exc_b<false>, dim3(EXB_QUAD / 2 + EXB_WAVE / 2), dim3(128), 0, s, t, a, w);
 }
 void launch_scan(const BatchArgs& a, const Workspace& w, hipStream_t s) {

@@ -111,7 +111,7 @@ def test_long_words_exception_path(small_byte):
     rng = random.Random(11)
     docs = []
     for n in [47, 48, 49, 50, 62, 63, 64, 65, 100, 126, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 300, 1000, 1023, 1024,
-              1025, 1500, 3000, 9000]:
+              1025, 1500, 2045, 2046, 2047, 2048, 2049, 3000, 9000]:
         docs.append(bytes(rng.choice(b"etaoinshr") for _ in range(n)))
         docs.append(b"pre " + bytes(rng.choice(b"etaoin") for _ in range(n)) + b" post")
         docs.append(("漢" * (n // 3 + 1)).encode("utf-8"))
@@ -156,7 +156,8 @@ def test_words_of_65_to_1024_units(vg_files, vl_files, small_byte, oracle_mod):
     that owns two changed blocks searches all of its blocks); the prefix units of a character vocabulary in front."""
     from hutoken_amd import synth
     rng = random.Random(65256)
-    lengths = list(range(60, 262)) * 2 + list(range(505, 520)) + list(range(1015, 1030)) + [rng.randrange(257, 1025) for _ in range(60)]
+    lengths = (list(range(60, 262)) * 2 + list(range(505, 520)) + list(range(1015, 1030)) + list(range(2040, 2052))
+               + [rng.randrange(257, 1025) for _ in range(60)] + [rng.randrange(1025, 2300) for _ in range(20)])
     letters = [bytes(rng.choice(b"etaoinshrdlucmfw") for _ in range(n)) for n in lengths]
     rng.shuffle(letters)
     # words of the corpus glued together: they merge back into their tokens, a dozen bytes and more each
@@ -165,11 +166,11 @@ def test_words_of_65_to_1024_units(vg_files, vl_files, small_byte, oracle_mod):
     words = [w for w in words if w.decode("utf-8").isalpha() and max(map(ord, w.decode("utf-8"))) < 0x250]  # (one splitter class)
     glued = []
     for _ in range(300):
-        w, want = b"", rng.randrange(65, 257) if rng.random() < 0.6 else rng.randrange(257, 1025)
+        w, want = b"", rng.randrange(65, 257) if rng.random() < 0.6 else rng.randrange(257, 2200)
         while len(w) < want:
             w += rng.choice(words)
         glued.append(w[:want].decode("utf-8", "ignore").encode("utf-8"))
-    same = [bytes([c]) * n for c in b"ae" for n in (65, 128, 129, 200, 256, 257, 512, 513, 1024, 1025)]
+    same = [bytes([c]) * n for c in b"ae" for n in (65, 128, 129, 200, 256, 257, 512, 513, 1024, 1025, 2046, 2047, 2048)]
     docs = [b" ".join(letters[i:i + 7]) for i in range(0, len(letters), 7)]
     docs += [b" ".join(glued[i:i + 5]) for i in range(0, len(glued), 5)]
     docs += [b"x " + w + b" y" for w in same] + letters[:40] + glued[:40]
