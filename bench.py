@@ -210,9 +210,11 @@ def secondary_runs(dev, dev_index, cores, no_verify):
               lambda: synth.random_words(17, 31, 200_000, 20), None, None),
              ("random words of 33-62 letters x VG (every word through the exception kernels)", "VG", False,
               lambda: synth.random_words(33, 62, 200_000, 10), None, None),
-             ("random words of 70-120 letters x VG (exception kernels: one lane per word, up to 256 units)", "VG", False,
+             ("random words of 70-120 letters x VG (exception kernels: two lanes per word, 32 words per wavefront)", "VG", False,
               lambda: synth.random_words(70, 120, 100_000, 8), None, None),
-             ("random words of 300-900 letters x VG (exception kernels: one wavefront per word)", "VG", False,
+             ("random words of 130-250 letters x VG (exception kernels: four lanes per word)", "VG", False,
+              lambda: synth.random_words(130, 250, 50_000, 8), None, None),
+             ("random words of 300-900 letters x VG (exception kernels: eight / sixteen lanes per word)", "VG", False,
               lambda: synth.random_words(300, 900, 20_000, 8), None, None),
              ("CJK paragraphs x VG (words of 300-1200 bytes under the reference's splitter; seams cut them)", "VG", False,
               lambda: synth.cjk_paragraphs(60_000), None, None),

@@ -1466,7 +1466,10 @@ __device__ __forceinline__ int64_t bpe_wave(const DevTables& T, Arr Sa, Arr Ma, 
     return n;
 }
 
-constexpr int EXC_CHUNK = 256;                    // positions examined per step when a word end is unknown
+#ifndef HUTK_EXC_CHUNK
+#define HUTK_EXC_CHUNK 256
+#endif
+constexpr int EXC_CHUNK = HUTK_EXC_CHUNK;                    // positions examined per step when a word end is unknown
 constexpr int EXC_WIN = 16 + EXC_CHUNK + 16;      // staged bytes per step
 
 // The same merge rule for words too long for the LDS arrays (up to MAX_WORD_BYTES units), in time
