@@ -336,7 +336,7 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     HIP_TRY(c->w_exc_tok.reserve(exc_elems));
     HIP_TRY(c->w_exc_sym.reserve(exc_elems));
     HIP_TRY(c->w_exc_mrg.reserve(exc_elems));
-    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 7 + n_tiles / 32 + 16));
+    HIP_TRY(c->w_tile_u32.reserve((size_t)n_tiles * 8 + n_tiles / 32 + 16));
     HIP_TRY(c->w_tile_i64.reserve((size_t)n_tiles * 2 + n_tiles / 2048 + 16));
     HIP_TRY(c->w_doc_pos.reserve((size_t)n_docs + 2));
     if (!c->w_counters.p) {  // (zeroed once: counters[10], k_pre's sample, is zeroed for the NEXT call by k_scan / k_tail_small)
@@ -363,7 +363,8 @@ int ensure_workspace(hutk_ctx* c, int64_t n_bytes, int64_t n_docs, int64_t n_til
     W.tile_nexc = u + 4 * n_tiles;
     W.exc_tiles = u + 5 * n_tiles;
     W.tile_lastreal = u + 6 * n_tiles;
-    W.noreal_bits = u + 7 * n_tiles;
+    W.tile_first_start = u + 7 * n_tiles;
+    W.noreal_bits = u + 8 * n_tiles;
     W.tile_first_doc = c->w_tile_i64.p;
     W.tile_base = c->w_tile_i64.p + n_tiles;
     W.scan_state = reinterpret_cast<unsigned long long*>(c->w_tile_i64.p + 2 * n_tiles + 2);

@@ -117,6 +117,7 @@ struct Workspace {
     uint32_t* counters;        // [0] exception total, [1] tiles with exceptions (one 64-bit atomic claims both), [2] d_exc's work cursor, [3] d_exc_lane_fast<1>'s (k_exc_a), [8] [9] [14] [15] d_exc_group_fast<2>'s .. <16>'s (k_exc_b), [4] / [5] entries of exc_quad / exc_wave, [6] tiles without a start of the reference's own, [7] k_scan's ticket
     uint32_t* exc_tiles;       // [n_tiles] those tiles, in no particular order
     uint32_t* noreal_bits;     // [n_tiles / 32 + 1] bit t: tile t holds no word start of the reference's own (k_cut)
+    uint32_t* tile_first_start;  // [n_tiles] first word start (seams and document starts included) among the tile's 1024 classified positions, 0xFFFF: none -- d_exc_ends finds the end of a word its tile could not see here
     uint32_t* tile_lastreal;   // [n_tiles] position of the tile's last such start | ids before it << 16 (written when none follows in the halo)
     int64_t cap_exc;
     int32_t pad_per_doc;       // extra exc_* slots per document (prefix units + prefix-alone ids)

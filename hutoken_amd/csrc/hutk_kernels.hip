@@ -487,6 +487,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(size
             }
             if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
         }
+        {   // the tile's first word start, for the words of EARLIER tiles that end here (d_exc_ends)
+            const unsigned long long sb_ = __ballot((flags & 0xFFFFu) != 0);
+            const int l0 = sb_ ? __builtin_ctzll(sb_) : 0;
+            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)flags, l0) & 0xFFFFu;
+            if (lane == 0 && tile_ok) W.tile_first_start[tile] = sb_ ? (uint32_t)(16 * l0 + __builtin_ctz(f0)) : 0xFFFFu;
+        }
         wmask16[lane] = (uint16_t)flags;
 #if HUTK_PERTURB_VALU
         {   // MEASUREMENT ONLY: extra VALU instructions (a dependent chain, every lane) -- is the kernel bound by VALU issue?
@@ -2803,9 +2809,6 @@ constexpr uint32_t ENDS_SHARE = 1;  // wavefronts that share the words of one ti
 __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
                                            uint32_t vgrid, uint8_t* lds) {
     EndsLds& L = *reinterpret_cast<EndsLds*>(lds);
-    uint8_t* const sb = L.sb;
-    uint8_t* const scode = L.scode;
-    uint32_t* const docm = L.docm;
     uint32_t* const lq = L.lq;
     uint32_t* const lm = L.lm;
     uint32_t* const lw = L.lw;
@@ -2836,38 +2839,47 @@ __device__ __forceinline__ void d_exc_ends(const DevTables& T, const BatchArgs& 
         const uint32_t tile = W.exc_tiles[ti];
         const uint32_t first = W.tile_exc_first[tile], nexc = W.tile_nexc[tile];
         if (max(max(nl[0] + nl[1], nl[2] + nl[3]), nl[4]) + nexc > (uint32_t)ENDS_LIST) flush();
-        EndsWin cw;
-        // the tile's records sixty-four at a time, their lengths read together: only the words of unknown length are walked
-        // (one record after the other, each a dependent load, cost a tile of ten long words ~10 us for the ONE whose end it
-        // could not see: k_exc_a 0.69 ms on 800 k words of 70-120 letters)
+        // The tile's records sixty-four at a time, ONE LANE PER WORD of unknown length.  Its end is the first word start of
+        // the tiles behind (tile_first_start: what every tile found among its own 1024 positions, seams and document starts
+        // included -- my tile saw none between the word and its window's end): one load for a word that ends in the next
+        // tile.  (Rounds 2-4 staged and classified the text again here, 256 positions at a time, a wavefront per word:
+        // k_exc_a was 1.0 of 3.3 ms on CJK paragraphs without seams, 0.5 of 2.3 on words of 70-120 letters.)
         static_assert(ENDS_SHARE == 1, "one wavefront per tile");
-        for (uint32_t e0 = 0; e0 < nexc; e0 += 64)
-        for (unsigned long long um = __ballot(e0 + lane < nexc && (int64_t)(first + e0 + lane) < W.cap_exc && W.exc[first + e0 + lane].len < 0);
-             um; um &= um - 1) {
-            const uint32_t idx = first + e0 + (uint32_t)__builtin_ctzll(um);
-            const ExcRec rec = W.exc[idx];
-            const int64_t ws = rec.ws;
-            const int64_t d = doc_of(A, W, ws, rec.tile), ds = A.offsets[d], de = A.offsets[d + 1];
-            bool too_large;
-            const int64_t we = exc_word_end(T, A, ws, d, ds, de, sb, scode, docm, lane, &too_large, cw);
-            const int64_t nb = too_large ? 0 : we - ws;
-            if (too_large || nb > MAX_WORD_BYTES) {
-                if (lane == 0) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        for (uint32_t e0 = 0; e0 < nexc; e0 += 64) {
+            const uint32_t idx = first + e0 + lane;
+            const bool unk = e0 + lane < nexc && (int64_t)idx < W.cap_exc && W.exc[idx].len < 0;
+            int list = -1;
+            if (unk) {
+                const int64_t ws = W.exc[idx].ws;
+                int64_t we = -1;
+                // (a word over the reference's limit of MAX_WORD_BYTES ends the search: it is refused below whatever its end)
+                const int64_t u_end = min((int64_t)A.n_tiles, (int64_t)tile + 3 + MAX_WORD_BYTES / TILE_BYTES);
+                for (int64_t u = (int64_t)tile + 1; u < u_end; u++) {
+                    const uint32_t fs = W.tile_first_start[u];
+                    if (fs != 0xFFFFu) { we = u * TILE_BYTES + fs; break; }
+                }
+                if (we < 0) we = u_end < A.n_tiles ? ws + MAX_WORD_BYTES + 1 : A.n_bytes;  // (no start within the limit / up to the text's end)
+                if (we > A.n_bytes) we = A.n_bytes;
+                const int64_t nb = we - ws;
+                if (nb > MAX_WORD_BYTES) {
+                    const int64_t d = doc_of(A, W, ws, tile), ds = A.offsets[d];
                     raise(A.err, HUTK_E_WORD_TOO_LARGE);
                     if (A.status) A.status[d] = HUTK_DOC_WORD_TOO_LARGE;
                     W.exc[idx].cnt = 0;
                     W.exc[idx].tok_base = -(ws - ds) - 1;  // where the document is cut (negative marks "no ids")
+                } else {
+                    W.exc[idx].len = (int32_t)nb;
+                    // (the list by the length with the prefix, whether or not this word gets it: d_exc_group_fast<NW> takes its list whole)
+                    list = exc_list_of(T, nb + T.n_prefix);
                 }
-                continue;
-            }
-            // (the list by the length with the prefix, whether or not this word gets it: d_exc_group_fast<NW> takes its list whole)
-            const int list = exc_list_of(T, nb + T.n_prefix);
-            if (lane == 0) {
-                W.exc[idx].len = (int32_t)nb;
-                *lds_slot(list, nl[list == 0 ? 0 : list == 1 ? 1 : list == 2 ? 2 : list == 3 ? 3 : 4]) = idx;
             }
 #pragma unroll
-            for (int l = 0; l < 5; l++) nl[l] += list == l;
+            for (int l = 0; l < 5; l++) {
+                const unsigned long long bl = __ballot(list == l);
+                if (list == l) *lds_slot(l, nl[l] + (uint32_t)__popcll(bl & below)) = idx;
+                nl[l] += (uint32_t)__popcll(bl);
+            }
         }
     }
     if (nl[0] | nl[1] | nl[2] | nl[3] | nl[4]) flush();

@@ -476,6 +476,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
             }
             if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
         }
+        {   // the tile's first word start, for the words of EARLIER tiles that end here (d_exc_ends)
+            const unsigned long long sb_ = __ballot((flags & 0xFFFFu) != 0);
+            const int l0 = sb_ ? __builtin_ctzll(sb_) : 0;
+            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)flags, l0) & 0xFFFFu;
+            if (lane == 0) W.tile_first_start[tile] = sb_ ? (uint32_t)(16 * l0 + __builtin_ctz(f0)) : 0xFFFFu;
+        }
         wmask16[lane] = (uint16_t)flags;
         wave_sync();
 

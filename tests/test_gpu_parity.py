@@ -182,6 +182,29 @@ def test_words_of_65_to_1024_units(vg_files, vl_files, small_byte, oracle_mod):
         _compare(ctx, orc, docs[:120], "65-256 small")
 
 
+def test_word_ends_in_later_tiles(vg_files, small_byte, oracle_mod):
+    """d_exc_ends: a word whose end its tile cannot see ends at the first word start of the tiles behind it
+    (Workspace::tile_first_start): words that end exactly on tile limits (multiples of 960 bytes), one to three tiles
+    further on, at a document's end, at the end of the batch, with another long word or nothing behind."""
+    rng = random.Random(960)
+    def word(n):
+        return bytes(rng.choice(b"etaoinshrdlu") for _ in range(n))
+    docs = []
+    for lead in (0, 1, 5, 63, 64, 100, 500, 896, 897, 959, 960, 961, 1000):
+        for n in (64, 65, 100, 959 - lead % 960, 960, 961, 1024, 1025, 1919, 1920, 1921, 2880, 3000):
+            if n < 64:
+                continue
+            pre = (word(lead - 1) + b" ") if lead else b""
+            docs.append(pre + word(n))                  # the document ends with the word
+            docs.append(pre + word(n) + b" x")          # a short word behind
+            docs.append(pre + word(n) + b" " + word(n))  # a long one behind
+    docs.append(word(70))      # the batch ends with a long word
+    vp, sp, kw = vg_files
+    _compare(_ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]), oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"]), docs, "ends VG")
+    for ctx, orc in small_byte[:2]:
+        _compare(ctx, orc, docs[::3] + [word(5000)], "ends small")
+
+
 def test_dense_word_tiles(small_byte):
     """Tiles packed with the shortest possible words: every byte a word (newlines, stray bytes), and
     two-byte words back to back (the most multi-unit words a tile can start)."""
