@@ -3271,19 +3271,28 @@ __device__ __forceinline__ void d_gather(const DevTables& T, const BatchArgs& A,
 }
 
 // Tiles with exception words, from the list k_tiles made: their ids are interleaved with the dense run.
+// CAP: exception words of a tile the wavefront's LDS arrays hold.  k_finish runs FOUR wavefronts per workgroup on tiles of
+// up to GATHER_EXC_SMALL words (BIG = -1: the others are skipped), then its first wavefront on the rest with the four
+// areas as one (BIG = 1: only tiles of more than GATHER_EXC_SMALL words) -- a tile is eight dependent stages of a few
+// loads each, so the wavefronts in flight set the pace, and 18 KB for each meant eight per CU (round 4: 0.40 -> 0.2 ms on
+// 80 k tiles of 70-120-letter words).  BIG = 0: every tile (k_tail_small).
+constexpr int GATHER_EXC_SMALL = 256;
+constexpr size_t gather_exc_lds(int cap) { return (size_t)cap * 4 + ((size_t)cap + 1) * 4 + 4 + (size_t)cap * 8 + (size_t)cap * 2; }
+template <int CAP, int BIG>
 __device__ __forceinline__ void d_gather_exc(const DevTables& T, const BatchArgs& A, const Workspace& W, uint32_t vblock,
-                                             uint32_t vgrid) {
-    __shared__ uint32_t e_pos[GATHER_EXC_LDS];
-    __shared__ uint32_t e_cum[GATHER_EXC_LDS + 1];
-    __shared__ int64_t e_tok[GATHER_EXC_LDS];
-    __shared__ uint16_t e_ws[GATHER_EXC_LDS];  // start of the word inside the tile
-    const int tid = threadIdx.x;
+                                             uint32_t vgrid, uint8_t* lds) {
+    int64_t* const e_tok = reinterpret_cast<int64_t*>(lds);                      // (the 8-byte array first: alignment)
+    uint32_t* const e_pos = reinterpret_cast<uint32_t*>(e_tok + CAP);
+    uint32_t* const e_cum = e_pos + CAP;                                          // CAP + 1 (+ 1 unused: keeps e_ws 8-byte aligned)
+    uint16_t* const e_ws = reinterpret_cast<uint16_t*>(e_cum + CAP + 2);         // start of the word inside the tile
+    const int tid = threadIdx.x & 63;
     const uint32_t n_list = W.counters[1];
     for (uint32_t li = vblock; li < n_list; li += vgrid) {
     const int64_t tile = W.exc_tiles[li];
+    const uint32_t nexc = W.tile_nexc[tile];
+    if (BIG != 0 && (nexc > (uint32_t)GATHER_EXC_SMALL) != (BIG > 0)) continue;
     const int64_t base = W.tile_base[tile];
     const uint32_t dense = W.tile_dense[tile];
-    const uint32_t nexc = W.tile_nexc[tile];
     // the run holds 16-bit symbols when the LDS arrays do (T.sym16), else 32-bit ones
     const uint16_t* run16 = reinterpret_cast<const uint16_t*>(W.run) + tile * RUN_STRIDE + W.tile_run_start[tile];
     const uint32_t* run32 = W.run + tile * RUN_STRIDE + W.tile_run_start[tile];
@@ -3386,8 +3395,16 @@ __global__ __launch_bounds__(64 * GATHER_WAVES) void k_finish(DevTables T, Batch
     if (b < g_gather) {
         d_gather<RunT>(T, A, W, (int64_t)b * GATHER_WAVES + (threadIdx.x >> 6));
     } else if (b < g_gather + FINISH_EXC_BLOCKS) {
-        if (threadIdx.x < GATHER_THREADS && W.counters[1] != 0)  // (a workgroup's first wavefront; uniform per wavefront)
-            d_gather_exc(T, A, W, b - g_gather, FINISH_EXC_BLOCKS);
+        __shared__ __attribute__((aligned(16))) uint8_t lds_exc[cmax(GATHER_WAVES * ((gather_exc_lds(GATHER_EXC_SMALL) + 15) & ~(size_t)15), gather_exc_lds(GATHER_EXC_LDS))];
+        if (W.counters[1] != 0) {  // (uniform: the barrier below is safe)
+            const uint32_t wv = threadIdx.x >> 6;
+            d_gather_exc<GATHER_EXC_SMALL, -1>(T, A, W, (b - g_gather) * GATHER_WAVES + wv, FINISH_EXC_BLOCKS * GATHER_WAVES,
+                                               lds_exc + wv * ((gather_exc_lds(GATHER_EXC_SMALL) + 15) & ~(size_t)15));
+            __syncthreads();
+            if (wv == 0)  // the tiles my four wavefronts skipped
+                for (uint32_t w4 = 0; w4 < (uint32_t)GATHER_WAVES; w4++)
+                    d_gather_exc<GATHER_EXC_LDS, 1>(T, A, W, (b - g_gather) * GATHER_WAVES + w4, FINISH_EXC_BLOCKS * GATHER_WAVES, lds_exc);
+        }
     } else {
         d_doc_off(A, W, (int64_t)(b - g_gather - FINISH_EXC_BLOCKS));
     }
@@ -3570,7 +3587,10 @@ __global__ __launch_bounds__(64) void k_tail_small(DevTables T, BatchArgs A, Wor
     }
     stage_done();
     for (int64_t w = 0; w * GATHER_TILES < A.n_tiles; w++) d_gather<SymT>(T, A, W, w);
-    if (W.counters[1] != 0) d_gather_exc(T, A, W, 0, 1);
+    if (W.counters[1] != 0) {
+        __shared__ __attribute__((aligned(16))) uint8_t lds_exc[gather_exc_lds(GATHER_EXC_LDS)];
+        d_gather_exc<GATHER_EXC_LDS, 0>(T, A, W, 0, 1, lds_exc);
+    }
     stage_done();  // (d_gather_exc writes the exception records' output positions; nothing below reads them, but keep the stages uniform)
     for (int64_t vb = 0; vb * 64 <= A.n_docs; vb++) d_doc_off(A, W, vb);
 }

@@ -205,6 +205,21 @@ def test_word_ends_in_later_tiles(vg_files, small_byte, oracle_mod):
         _compare(ctx, orc, docs[::3] + [word(5000)], "ends small")
 
 
+def test_many_exception_words_in_one_tile(vl_files, small_char, oracle_mod):
+    """k_finish's d_gather_exc: tiles of more than 256 exception words (documents of one to three bytes under a prefix
+    vocabulary: every document's first word is one) take the second pass with the workgroup's whole LDS; mixed with
+    tiles of a few."""
+    rng = random.Random(256)
+    tiny = [bytes(rng.choice(b"abcdeghi") for _ in range(rng.randrange(1, 4))) for _ in range(6000)]
+    mixed = tiny[:1500] + [b"some longer document with a few words in it " * 3] * 40 + tiny[1500:3000]
+    vp, sp, kw = vl_files
+    ctx, orc = _ctx(vp, sp, kw["prefix"], kw["is_byte_encoder"]), oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    _compare(ctx, orc, tiny, "tiny VL")
+    _compare(ctx, orc, mixed, "mixed VL")
+    for c, o in small_char:
+        _compare(c, o, mixed, "mixed small")
+
+
 def test_dense_word_tiles(small_byte):
     """Tiles packed with the shortest possible words: every byte a word (newlines, stray bytes), and
     two-byte words back to back (the most multi-unit words a tile can start)."""
