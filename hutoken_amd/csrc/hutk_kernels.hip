@@ -29,10 +29,12 @@
 //              staged window, beyond the tile's prefix budget) become exception records.
 //   k_exc_a    exception words of up to 63 bytes, one LANE per word (d_exc_lane_fast<1>: one dword per unit, rows read
 //              16 bytes at a time; d_exc_medium for vocabularies without the short form); the ends of the words whose
-//              end no tile saw (d_exc_ends)
-//   k_exc_b    words of up to 256 units: one lane per word again, 16 or 8 words per wavefront (d_exc_lane_fast<2>, <4>;
-//              d_exc_quad, sixteen lanes per word, for 32-bit symbols); longer ones: one wavefront per word (d_exc: up to
-//              1024 units in LDS, beyond that in HBM with dead-unit marks and per-chunk minima, bpe_wave_big)
+//              end no tile saw (d_exc_ends: the first word start of the tiles behind, Workspace::tile_first_start) and
+//              the five lists by length for k_exc_b
+//   k_exc_b    words of up to 1024 units: TWO .. SIXTEEN lanes per word, 32 .. 4 words per wavefront (d_exc_group_fast<2>
+//              .. <16>: block minima in registers; d_exc_quad, sixteen lanes per word up to 256 units, for 32-bit
+//              symbols); longer ones: one wavefront per word (d_exc: up to 2046 / 1024 units in LDS, beyond that in HBM
+//              with dead-unit marks and per-chunk minima, bpe_wave_big)
 //   k_cut      the reference's over-long-word rule (a document ends in front of a word of more than 262144 bytes)
 //   k_scan     exclusive scan of per-tile id counts, one launch, decoupled look-back with tickets
 //   k_finish   tile runs -> caller's ids array (symbol -> id), also for the tiles that hold exception words; out_offsets[]
