@@ -22,7 +22,7 @@ EXPORTS = [
     "hutk_host_free", "hutk_decode_batch", "hutk_decode_batch_device",
     "hutk_pair_table_entries", "hutk_device_ordinal", "hutk_table_stats", "hutk_last_timing",
     "hutk_set_timing", "hutk_debug_pairs_second", "hutk_debug_long_words", "hutk_debug_profile", "hutk_debug_profile_read", "hutk_debug_profile_raw", "hutk_debug_tile_bytes",
-    "hutk_debug_seam",
+    "hutk_debug_seam", "hutk_debug_seam2_cut",
 ]
 
 _lib = None
@@ -123,6 +123,9 @@ def load(build_if_missing=True):
     if hasattr(L, "hutk_debug_seam"):
         L.hutk_debug_seam.restype = i32
         L.hutk_debug_seam.argtypes = [vp, vp]
+    if hasattr(L, "hutk_debug_seam2_cut"):
+        L.hutk_debug_seam2_cut.restype = i32
+        L.hutk_debug_seam2_cut.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.hutk_debug_profile.restype = i32
     L.hutk_debug_profile.argtypes = [vp, i32]
     L.hutk_debug_tile_bytes.restype = i32
@@ -291,6 +294,10 @@ class Context:
         out = np.zeros(256, dtype=np.uint32)
         on = load().hutk_debug_seam(self._h, out.ctypes.data)
         return out, bool(on)
+
+    def seam2_cut(self, a3, b3):
+        """The seam map's second level: True when no token can span the three-byte characters a3 | b3 (bytes objects)."""
+        return bool(load().hutk_debug_seam2_cut(self._h, int.from_bytes(a3, "little"), int.from_bytes(b3, "little")))
 
     def encode_packed(self, data, offsets, want_status=True):
         """Host numpy buffers in, host numpy buffers out.

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 INCLUDE = os.path.join(ROOT, "include")
 
 HIP_SOURCES = ["hutk_loader.cpp", "hutk_api.cpp", "hutk_kernels.hip", "hutk_ptiles.hip", "hutk_decode.hip"]
-HIP_HEADERS = ["hutk_internal.h", "hutk_kdev.h", "hutk_device.h", "hutk_classify.h", "hutk_lab.h", os.path.join(INCLUDE, "hutoken_amd.h")]
+HIP_HEADERS = ["hutk_internal.h", "hutk_seam2.h", "hutk_kdev.h", "hutk_device.h", "hutk_classify.h", "hutk_lab.h", os.path.join(INCLUDE, "hutoken_amd.h")]
 
 LIB_HIP = os.path.join(LIBDIR, "libhutoken_amd.so")
 LIB_SYNTH = os.path.join(LIBDIR, "libhutk_synth.so")

@@ -84,7 +84,7 @@ struct hutk_ctx {
     // device tables
     DevBuf<uint64_t> d_pair, d_char;
     DevBuf<int32_t> d_sym_id, d_prefix_alone;
-    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms, d_seam, d_item_units;
+    DevBuf<uint32_t> d_item_sym, d_prefix_syms, d_prefix_alone_syms, d_seam, d_seam2, d_item_units;
     DevBuf<uint8_t> d_item_direct, d_split_dfa;
     DevBuf<uint32_t> d_bytepair16;  // {symbol, merged} as 16 + 16 bits
     DevBuf<WordSlot> d_word_tab;
@@ -221,6 +221,18 @@ int upload_tables(hutk_ctx* c) {
     HIP_TRY(hipMemcpy(c->d_seam.p, T.seam_hi, sizeof T.seam_hi, hipMemcpyHostToDevice));
     D.seam_hi = c->d_seam.p;
     D.seam_on = T.seam_on && !(getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ? 1 : 0;
+    {   // second level: seam2_part, then the hashed set of character pairs, in one buffer
+        const size_t nb = T.seam2_on ? T.seam2_bits.size() : 1;
+        std::vector<uint32_t> buf(256 + nb, 0u);
+        memcpy(buf.data(), T.seam2_part, sizeof T.seam2_part);
+        if (T.seam2_on) memcpy(buf.data() + 256, T.seam2_bits.data(), nb * 4);
+        HIP_TRY(c->d_seam2.reserve(buf.size()));
+        HIP_TRY(hipMemcpy(c->d_seam2.p, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+        D.seam2_part = c->d_seam2.p;
+        D.seam2_bits = c->d_seam2.p + 256;
+        D.seam2_shift = T.seam2_shift;
+        D.seam2_on = D.seam_on && T.seam2_on && !(getenv("HUTK_NO_SEAM2") && atoi(getenv("HUTK_NO_SEAM2"))) ? 1 : 0;
+    }
     {   // multi bits [8], unit offsets [257], units: one allocation
         std::vector<uint32_t> iu(T.multi_bits, T.multi_bits + 8);
         iu.insert(iu.end(), T.item_units_off, T.item_units_off + 257);
@@ -395,7 +407,7 @@ void destroy(hutk_ctx* c) {
     if (!c->host_only && c->device >= 0) {
         (void)hipSetDevice(c->device);
         c->d_pair.release(); c->d_char.release(); c->d_sym_id.release(); c->d_prefix_alone.release();
-        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release(); c->d_item_units.release();
+        c->d_item_sym.release(); c->d_prefix_syms.release(); c->d_prefix_alone_syms.release(); c->d_item_direct.release(); c->d_split_dfa.release(); c->d_seam.release(); c->d_seam2.release(); c->d_item_units.release();
         c->d_bytepair16.release(); c->d_bytepair32.release(); c->w_prof.release();
         c->d_word_tab.release(); c->w_wbits.release(); c->w_gbits.release(); c->w_fbits.release(); c->w_abits.release();
         c->w_run.release(); c->w_exc_tok.release(); c->w_exc_sym.release(); c->w_exc_mrg.release();
@@ -619,6 +631,19 @@ int hutk_debug_seam(const hutk_ctx* ctx, uint32_t* out256) {
     if (!ctx || !out256) return set_err(HUTK_E_ARG, "bad argument");
     memcpy(out256, ctx->tab.seam_hi, sizeof ctx->tab.seam_hi);
     return ctx->tab.seam_on && !(getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ? 1 : 0;
+}
+// second level: 1 when it is on and says that NO token can span the boundary between the three-byte characters a3 | b3
+// (little-endian 24-bit values) -- asked where hutk_debug_seam's map says "may join"; 0 otherwise
+int hutk_debug_seam2_cut(const hutk_ctx* ctx, uint32_t a3, uint32_t b3) {
+    if (!ctx) return 0;
+    const Tables& T = ctx->tab;
+    if (!T.seam_on || !T.seam2_on || (getenv("HUTK_NO_SEAM") && atoi(getenv("HUTK_NO_SEAM"))) ||
+        (getenv("HUTK_NO_SEAM2") && atoi(getenv("HUTK_NO_SEAM2"))))
+        return 0;
+    if (!seam2_char3(a3) || !seam2_char3(b3)) return 0;
+    if ((T.seam2_part[(a3 >> 16) & 0xFFu] >> (b3 & 31u)) & 1u) return 0;
+    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
+    return ((T.seam2_bits[h >> 5] >> (h & 31)) & 1u) ? 0 : 1;
 }
 void hutk_set_timing(hutk_ctx* ctx, int enabled) {
     if (ctx) ctx->timing = enabled != 0;

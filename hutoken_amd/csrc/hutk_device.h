@@ -74,6 +74,11 @@ struct DevTables {
     // of its own starts at y (k_tiles, exc_word_end).  seam_on == 0: never split (regex path, HUTK_NO_SEAM=1)
     const uint32_t* seam_hi;
     int32_t seam_on;
+    // second level (Tables::seam2_*): whole characters A | B where seam_hi says "may join"
+    const uint32_t* seam2_bits;
+    const uint32_t* seam2_part;
+    uint32_t seam2_shift;
+    int32_t seam2_on;
     // items with a replacement of several units, or of none (Tables::multi_bits): bit b of multi_bits[8]; the units of
     // item b are item_units[item_units_off[b] .. item_units_off[b + 1]).  has_multi == 0: every item is one unit.
     // unit_scale = most units one input item can become: exception words own unit_scale slots per byte.

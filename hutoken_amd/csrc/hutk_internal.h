@@ -1,5 +1,6 @@
 // hutk_internal.h -- shared between the host loader, the C-ABI and the kernels.
 #pragma once
+#include "hutk_seam2.h"
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -181,6 +182,16 @@ struct Tables {
     // the tile kernel starts a word of its own at y (hutk_loader.cpp, seam_from_pairs).
     uint32_t seam_hi[256] = {0};
     bool seam_on = false;
+    // Second level, consulted where seam_hi says "may join" and both sides of the boundary are whole three-byte characters A | B
+    // (hutk_loader.cpp, seam2_build): a merge can join across A | B only if seam2_part[last byte of A] has B's lead byte's bit
+    // (entries whose left side does not end, or whose right side does not begin, with a whole three-byte character) or bit
+    // seam2_hash(A, B) >> seam2_shift of seam2_bits is set (entries that do: a hashed set of character pairs; a false
+    // positive costs a cut, nothing else).  For vocabularies whose merges cover every (last byte, lead byte) pair but
+    // join only the character pairs of their frequent words (trained on CJK text).
+    std::vector<uint32_t> seam2_bits;
+    uint32_t seam2_part[256] = {0};
+    uint32_t seam2_shift = 0;
+    bool seam2_on = false;
 
     bool is_byte_encoder = false;
     bool has_prefix = false;

@@ -92,6 +92,19 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Seam map, second level (Tables::seam2_*): 24 bits at bit offset s (0..127) of the 16 bytes hi:lo, and the verdict for the
+// boundary between the three-byte characters a3 | b3 where the first level says "may join": true = no token spans it.
+__device__ __forceinline__ uint32_t win24(uint64_t lo, uint64_t hi, int s) {
+    const uint64_t r = s == 0 ? lo : s < 64 ? ((lo >> s) | (hi << (64 - s))) : (hi >> (s - 64));
+    return (uint32_t)r & 0xFFFFFFu;
+}
+__device__ __forceinline__ bool seam2_cuts(const DevTables& T, uint32_t a3, uint32_t b3) {
+    if (!seam2_char3(a3) || !seam2_char3(b3)) return false;
+    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
+    const uint32_t part = T.seam2_part[(a3 >> 16) & 0xFFu], bits = T.seam2_bits[h >> 5];  // (both loads in flight)
+    return !((part >> (b3 & 31u)) & 1u) && !((bits >> (h & 31u)) & 1u);
+}
+
 // __syncthreads() of a workgroup that is ONE wavefront, without the s_barrier: the same fences, so that what one lane wrote
 // (LDS or global memory) the others read afterwards -- for code that also runs as one of two independent wavefronts of a
 // workgroup (k_exc_b), where an s_barrier would tie them together.

@@ -46,6 +46,9 @@
 #ifndef HUTK_LAB_EXC_STAMPS
 #define HUTK_LAB_EXC_STAMPS 0  // 1: d_exc_group_fast<2> leaves its trips' cycle sums in the profile buffer (tools/exc_stamps.py)
 #endif
+#ifndef HUTK_LAB_SEAM2_TILES
+#define HUTK_LAB_SEAM2_TILES 0  // 1: the seam map's second level (whole characters) in k_tiles too, not in k_ptiles only: C3 226.0 -> 223.4 GB/s (8 rounds, one box), and text dense in three-byte characters is k_ptiles' anyway
+#endif
 #define HUTK_STR2(x) #x
 #define HUTK_STR(x) HUTK_STR2(x)
 #ifndef HUTK_LAB_LDS_PAD

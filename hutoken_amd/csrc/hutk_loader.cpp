@@ -447,6 +447,64 @@ void seam_from_pairs(Tables& T, const std::vector<uint64_t>& entries, const std:
     T.seam_on = true;
 }
 
+// Second level (Tables::seam2_*), byte-encoder mode, string-keyed path.  raw[s]: the input bytes of vocabulary symbol s when
+// every unit of its key is produced by exactly one input byte (empty: not known).  An entry (L, R) whose L ends with a whole
+// three-byte character A and whose R begins with one, B, can join two input bytes x | y only where the text reads A | B
+// there: it goes into the hashed set of character pairs.  Every other entry stays what it is in seam_hi: a (last byte,
+// lead byte) pair, in seam2_part.  So where the text reads A | B, both well-formed, a token across the boundary needs
+// seam2_part[A's last byte] bit (B's lead byte) or the pair (A, B) in the set.
+void seam2_build(Tables& T, const std::vector<uint64_t>& entries, const std::vector<RawEnds>& ends,
+                 const std::vector<std::string>& raw) {
+    T.seam2_on = false;
+    for (int x = 0; x < 256; x++) T.seam2_part[x] = 0;
+    T.seam2_bits.clear();
+    if (!T.seam_on || !T.is_byte_encoder || T.has_multi || T.has_prefix) return;
+    auto tail3 = [](const std::string& r, uint32_t* out) -> bool {
+        if (r.size() < 3) return false;
+        const size_t n = r.size();
+        const uint32_t c = (uint32_t)(unsigned char)r[n - 3] | ((uint32_t)(unsigned char)r[n - 2] << 8) | ((uint32_t)(unsigned char)r[n - 1] << 16);
+        *out = c;
+        return seam2_char3(c);
+    };
+    auto head3 = [](const std::string& r, uint32_t* out) -> bool {
+        if (r.size() < 3) return false;
+        const uint32_t c = (uint32_t)(unsigned char)r[0] | ((uint32_t)(unsigned char)r[1] << 8) | ((uint32_t)(unsigned char)r[2] << 16);
+        *out = c;
+        return seam2_char3(c);
+    };
+    std::vector<std::pair<uint32_t, uint32_t>> full;
+    for (uint64_t e : entries) {
+        const uint32_t l = (uint32_t)e & 0xFFFFFu, r = ((uint32_t)e >> 20) | (((uint32_t)(e >> 32) & 0xFFu) << 12);
+        if (l >= ends.size() || r >= ends.size()) continue;
+        const uint32_t f = ends[r].first_hi;
+        if (!f) continue;  // (R never begins with a byte >= 0xE0: no seam is asked about)
+        uint32_t a3 = 0, b3 = 0;
+        if (l < raw.size() && r < raw.size() && tail3(raw[l], &a3) && head3(raw[r], &b3)) {
+            full.push_back({a3, b3});
+            continue;
+        }
+        for (int q = 0; q < 4; q++)
+            for (uint64_t m = ends[l].last[q]; m; m &= m - 1) T.seam2_part[64 * q + __builtin_ctzll(m)] |= f;
+    }
+    if (getenv("HUTK_DEBUG_SEAM2")) {
+        size_t known = 0, part_bits = 0;
+        for (auto& r : raw) known += !r.empty();
+        for (int x = 0; x < 256; x++) part_bits += __builtin_popcount(T.seam2_part[x]);
+        fprintf(stderr, "seam2: %zu entries, %zu of whole characters, %zu of %zu symbols with known bytes, %zu bits in the part map\n",
+                entries.size(), full.size(), known, raw.size(), part_bits);
+    }
+    if (full.empty()) return;  // (nothing the first level does not say already)
+    uint32_t lg = 16;
+    while (lg < 24 && ((size_t)1 << lg) < full.size() * 32) lg++;
+    T.seam2_shift = 32 - lg;
+    T.seam2_bits.assign(((size_t)1 << lg) / 32, 0u);
+    for (auto& ab : full) {
+        const uint32_t h = seam2_hash(ab.first, ab.second) >> T.seam2_shift;
+        T.seam2_bits[h >> 5] |= 1u << (h & 31);
+    }
+    T.seam2_on = true;
+}
+
 // ------------------------------------------------------------------------
 // id-keyed merge path: a merges file was given (src/lib.c:573-663, src/core.c:211-337, 457-477)
 // ------------------------------------------------------------------------
@@ -1051,6 +1109,28 @@ LoadError load_tables(const char* vocab_path, const char* special_path, const ch
             e.join(U.get(us.back()), false, true);
         }
         seam_from_pairs(T, entries, ends);
+        // the symbols' input bytes, where every unit of the key has exactly ONE input byte that makes it
+        std::vector<std::string> raw(order.size());
+        if (is_byte_encoder && !T.has_multi) {
+            std::unordered_map<uint32_t, std::pair<int, int>> makers;  // unit symbol -> (input bytes that make it, one of them)
+            for (int b = 1; b < 256; b++) {
+                auto& m = makers[T.item_sym[b]];
+                m.first++;
+                m.second = b;
+            }
+            for (size_t i = 0; i < order.size(); i++) {
+                if (!split_units(*order[i].second, true, us) || us.empty()) continue;
+                std::string r;
+                for (auto& u : us) {
+                    auto it = sym_of.find(u);
+                    auto mk = it == sym_of.end() ? makers.end() : makers.find(it->second);
+                    if (mk == makers.end() || mk->second.first != 1) { r.clear(); break; }
+                    r.push_back((char)mk->second.second);
+                }
+                raw[i] = r;
+            }
+        }
+        seam2_build(T, entries, ends, raw);
     }
 
     // ---- keys as raw input bytes (whole-word table candidates) ----

@@ -453,13 +453,17 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                         const int sh = __builtin_ctzll(m0) - 7;
                         const uint32_t y = (uint32_t)(w.b >> sh) & 0xFFu, x = (uint32_t)(p0 >> sh) & 0xFFu;
                         const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_dfa + dfa::seam_offset(x));
-                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (sh >> 3);
+                        bool join = (sm >> (y & 31u)) & 1u;
+                        if (join && T.seam2_on) join = !seam2_cuts(T, win24(w.a, w.b, 40 + sh), win24(w.b, w.c, sh));  // whole characters
+                        if (!join) flags |= 1u << (sh >> 3);
                     }
                     for (; m1; m1 &= m1 - 1) {
                         const int sh = __builtin_ctzll(m1) - 7;
                         const uint32_t y = (uint32_t)(w.c >> sh) & 0xFFu, x = (uint32_t)(p1 >> sh) & 0xFFu;
                         const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_dfa + dfa::seam_offset(x));
-                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (8 + (sh >> 3));
+                        bool join = (sm >> (y & 31u)) & 1u;
+                        if (join && T.seam2_on) join = !seam2_cuts(T, win24(w.b, w.c, 40 + sh), win24(w.c, w.d, sh));
+                        if (!join) flags |= 1u << (8 + (sh >> 3));
                     }
                 }
             }

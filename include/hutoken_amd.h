@@ -219,6 +219,11 @@ int64_t hutk_debug_long_words(const hutk_ctx* ctx);
  * 211-337) can never produce a token across x | y, and the word is encoded as two.  Returns 1 when the map is in
  * use, 0 when it is switched off (HUTK_NO_SEAM=1). */
 int hutk_debug_seam(const hutk_ctx* ctx, uint32_t* out256);
+/* Diagnostic: the seam map's second level (vocabularies whose merges cover every (last byte, lead byte) pair but join only
+ * some pairs of whole characters).  a3, b3: the three bytes of the character in front of a boundary and of the one behind
+ * it, little-endian.  Returns 1 when no token can span a3 | b3 -- the tile kernel starts a word at b3 although the first
+ * level says "may join" -- and 0 otherwise (also when the level is off).  tests/test_seam_cpu.py. */
+int hutk_debug_seam2_cut(const hutk_ctx* ctx, uint32_t a3, uint32_t b3);
 
 /* Diagnostic build aid: clock64 stamps at the phase boundaries of the tile kernel.
  * hutk_debug_profile(ctx, 1), run a batch, then hutk_debug_profile_read returns the

@@ -32,8 +32,19 @@ def cjk_text(rng):
     return "".join(out)
 
 
-def pieces_of(word, seam):
-    cuts = [0] + [k for k in range(1, len(word)) if word[k] >= 0xE0 and not (int(seam[word[k - 1]]) >> (word[k] & 31)) & 1]
+def pieces_of(word, seam, ctx=None, count2=None):
+    """The word cut where the seam map allows: first level (byte pairs), and -- where that says "may join" and the context
+    has one -- the second level (whole three-byte characters on both sides, hutk_debug_seam2_cut)."""
+    cuts = [0]
+    for k in range(1, len(word)):
+        if word[k] < 0xE0:
+            continue
+        if not (int(seam[word[k - 1]]) >> (word[k] & 31)) & 1:
+            cuts.append(k)
+        elif ctx is not None and k >= 3 and k + 3 <= len(word) and ctx.seam2_cut(word[k - 3:k], word[k:k + 3]):
+            cuts.append(k)
+            if count2 is not None:
+                count2[0] += 1
     cuts.append(len(word))
     return [word[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
 
@@ -58,7 +69,7 @@ def check(vp, sp, prefix, is_byte, merges, rng, n_texts):
         st = O.split_words(doc)
         for j, s in enumerate(st):
             w = doc[s:(st[j + 1] if j + 1 < len(st) else len(doc))]
-            ps = pieces_of(w, seam)
+            ps = pieces_of(w, seam, ctx)
             if len(ps) == 1:
                 continue
             n_cut += 1
@@ -111,6 +122,46 @@ def test_shipped_vocabularies():
     assert check(vp, sp, kw["prefix"], kw["is_byte_encoder"], mp, rng, 200) > 100
 
 
+def test_second_level_on_a_vocabulary_dense_in_cjk_merges(monkeypatch):
+    """VC (trained on CJK text) has some merge across nearly every (last byte, lead byte) pair: the first level cuts almost
+    nothing.  The second level knows which pairs of WHOLE characters a merge joins: text of the vocabulary's own
+    distribution is cut where a rare pair stands, characters drawn at random almost everywhere -- and every piece-wise
+    encoding equals the word's."""
+    from hutoken_amd import synth
+    vp, sp, kw = data.vocab_files("VC")
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2)
+    seam, on = ctx.seam_map()
+    assert on
+    orc = O.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    head = len(orc.encode_bytes(b"\n")[0])
+    enc = lambda w: orc.encode_bytes(b"\n" + w)[0][head:]  # noqa: E731
+    rng = random.Random(77)
+    texts = []
+    d, o = synth.cjk_text(12)
+    texts += [d[o[i]:o[i + 1]].tobytes() for i in range(12)]
+    d, o = synth.cjk_paragraphs(6)
+    texts += [d[o[i]:o[i + 1]].tobytes() for i in range(6)]
+    pool = [chr(0x4E00 + rng.randrange(3000)) for _ in range(400)] + list("aé ,.1😂€")
+    texts += ["".join(rng.choice(pool) for _ in range(rng.randrange(5, 120))).encode("utf-8") for _ in range(150)]
+    n1 = [0]
+    n2 = [0]
+    for doc in texts:
+        st = O.split_words(doc)
+        for j, s0 in enumerate(st):
+            w = doc[s0:(st[j + 1] if j + 1 < len(st) else len(doc))]
+            ps = pieces_of(w, seam, ctx, n2)
+            if len(ps) == 1:
+                continue
+            n1[0] += 1
+            assert enc(w) == [i for p in ps for i in enc(p)], (w, ps)
+    assert n1[0] > 50 and n2[0] > 500  # (the second level does cut)
+    ctx.close()
+    monkeypatch.setenv("HUTK_NO_SEAM2", "1")
+    ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"], device=-2)
+    assert not ctx.seam2_cut("仟".encode(), "卽".encode())
+    ctx.close()
+
+
 def test_switch(monkeypatch):
     vp, sp, kw = data.vocab_files("VG")
     monkeypatch.setenv("HUTK_NO_SEAM", "1")
@@ -152,7 +203,7 @@ def test_hex_literals_beside_cjk_and_specials_on_lead_bytes(tmp_path):
         st = O.split_words(doc)
         for j, s in enumerate(st):
             w = doc[s:(st[j + 1] if j + 1 < len(st) else len(doc))]
-            ps = pieces_of(w, seam)
+            ps = pieces_of(w, seam, ctx)
             if len(ps) == 1:
                 continue
             n_cut += 1

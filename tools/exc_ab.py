@@ -3,7 +3,7 @@
 usage: exc_ab.py lib1.so lib2.so ..."""
 import os, subprocess, sys, re
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cases = [("words:17:31", "100000", "VG"), ("words:33:62", "100000", "VG"), ("words:300:900", "20000", "VG"), ("words:70:120", "100000", "VG"), ("words:130:250", "50000", "VG"), ("words:70:250", "20000", "VL"), ("cjk", "20000", "VG:noseam"), ("cjktext", "20000", "VC")]
+cases = [("words:17:31", "100000", "VG"), ("words:33:62", "100000", "VG"), ("words:300:900", "20000", "VG"), ("words:70:120", "100000", "VG"), ("words:130:250", "50000", "VG"), ("words:70:250", "20000", "VL"), ("cjk", "20000", "VG:noseam"), ("cjktext", "20000", "VC"), ("cjk", "20000", "VC")]
 if os.environ.get("EXC_AB_CASES"):
     cases = [c for c in cases if c[0] in os.environ["EXC_AB_CASES"].split(",")]
 code = r'''
