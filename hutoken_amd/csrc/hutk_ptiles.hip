@@ -228,7 +228,14 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
         const uint32_t n_dense = total & 0x7FFu, n_exc = (total >> 11) & 0x3FFu;
         static_assert(RUN_STRIDE < 2048 && TILE_BYTES < 1024, "count fields");
         const uint32_t exc_first = me.exc_first;
+        // the tile's first word start, for the words of EARLIER tiles that end here (d_exc_ends) -- here, not in the front end:
+        // there its three registers were two spills and 12 bytes of scratch, and a kernel with scratch is slow to leave
+        const uint32_t wm16 = reinterpret_cast<const uint16_t*>(me.wmask16)[lane];
+        const unsigned long long starts = __ballot(wm16 != 0);
+        const int l0 = starts ? __builtin_ctzll(starts) : 0;
+        const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)wm16, l0);
         if (lane == 0) {
+            W.tile_first_start[tile] = starts ? (uint32_t)(16 * l0 + __builtin_ctz(f0)) : 0xFFFFu;
             if (n_exc) W.exc_tiles[me.exc_list] = (uint32_t)tile;
             W.tile_count[tile] = n_dense;
             W.tile_dense[tile] = n_dense;
@@ -447,23 +454,51 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 const uint64_t K8 = 0x8080808080808080ull;
                 uint64_t m0 = w.b & (w.b << 1) & (w.b << 2) & K8;  // bytes >= 0xE0 among my positions 0..7
                 uint64_t m1 = w.c & (w.c << 1) & (w.c << 2) & K8;  // ... 8..15
+                uint32_t ask2 = 0;  // my positions the map leaves alone ("may join"): the second level's, below
                 if (m0 | m1) {
                     const uint64_t p0 = (w.b << 8) | (w.a >> 56), p1 = (w.c << 8) | (w.b >> 56);  // the byte in front of each
                     for (; m0; m0 &= m0 - 1) {
                         const int sh = __builtin_ctzll(m0) - 7;
                         const uint32_t y = (uint32_t)(w.b >> sh) & 0xFFu, x = (uint32_t)(p0 >> sh) & 0xFFu;
                         const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_dfa + dfa::seam_offset(x));
-                        bool join = (sm >> (y & 31u)) & 1u;
-                        if (join && T.seam2_on) join = !seam2_cuts(T, win24(w.a, w.b, 40 + sh), win24(w.b, w.c, sh));  // whole characters
-                        if (!join) flags |= 1u << (sh >> 3);
+                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (sh >> 3);
+                        else ask2 |= 1u << (sh >> 3);
                     }
                     for (; m1; m1 &= m1 - 1) {
                         const int sh = __builtin_ctzll(m1) - 7;
                         const uint32_t y = (uint32_t)(w.c >> sh) & 0xFFu, x = (uint32_t)(p1 >> sh) & 0xFFu;
                         const uint32_t sm = *reinterpret_cast<const uint32_t*>(s_dfa + dfa::seam_offset(x));
-                        bool join = (sm >> (y & 31u)) & 1u;
-                        if (join && T.seam2_on) join = !seam2_cuts(T, win24(w.b, w.c, 40 + sh), win24(w.c, w.d, sh));
-                        if (!join) flags |= 1u << (8 + (sh >> 3));
+                        if (!((sm >> (y & 31u)) & 1u)) flags |= 1u << (8 + (sh >> 3));
+                        else ask2 |= 1u << (8 + (sh >> 3));
+                    }
+                }
+                // Second level (Tables::seam2_*): whole three-byte characters A | B on both sides of such a boundary -- a lane has
+                // at most six lead bytes among its sixteen positions; their two loads each are all in flight before any is used
+                if (T.seam2_on && __any(ask2 != 0)) {
+                    for (uint32_t nn = ask2; __any(nn != 0);) {  // three at a time (registers), at most two rounds
+                        uint32_t part[3], bits[3], meta[3];      // meta: bit of the set | lead byte's bit << 5 | my position << 10
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            part[k] = bits[k] = 0xFFFFFFFFu;  // ("may join")
+                            meta[k] = 0;
+                            if (nn) {
+                                const int j = __builtin_ctz(nn);
+                                nn &= nn - 1;
+                                const int oa = j + 5, ob = j + 8;  // byte offsets of A and B in the 32-byte window
+                                const int qa = oa >> 3, qb = ob >> 3;
+                                const uint32_t a3 = win24(qa == 0 ? w.a : qa == 1 ? w.b : w.c, qa == 0 ? w.b : qa == 1 ? w.c : w.d, 8 * (oa & 7));
+                                const uint32_t b3 = win24(qb == 1 ? w.b : w.c, qb == 1 ? w.c : w.d, 8 * (ob & 7));
+                                if (seam2_char3(a3) && seam2_char3(b3)) {
+                                    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
+                                    part[k] = T.seam2_part[(a3 >> 16) & 0xFFu];
+                                    bits[k] = T.seam2_bits[h >> 5];
+                                    meta[k] = (h & 31u) | ((b3 & 31u) << 5) | ((uint32_t)j << 10);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+                            if (!((part[k] >> ((meta[k] >> 5) & 31u)) & 1u) && !((bits[k] >> (meta[k] & 31u)) & 1u)) flags |= 1u << (meta[k] >> 10);
                     }
                 }
             }
@@ -479,12 +514,6 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 zhi &= v <= 8 ? 0ull : ((1ull << (8 * (v - 8))) - 1ull);
             }
             if (zlo | zhi) raise(A.err, HUTK_E_NUL_BYTE);
-        }
-        {   // the tile's first word start, for the words of EARLIER tiles that end here (d_exc_ends)
-            const unsigned long long sb_ = __ballot((flags & 0xFFFFu) != 0);
-            const int l0 = sb_ ? __builtin_ctzll(sb_) : 0;
-            const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)flags, l0) & 0xFFFFu;
-            if (lane == 0) W.tile_first_start[tile] = sb_ ? (uint32_t)(16 * l0 + __builtin_ctz(f0)) : 0xFFFFu;
         }
         wmask16[lane] = (uint16_t)flags;
         wave_sync();
