@@ -229,7 +229,11 @@ def secondary_runs(dev, dev_index, cores, no_verify):
              ("ONE document of 1 GB x VG, whole (ids checked in tests/test_gpu_bigdoc.py, not here)", "VG", False,
               lambda: synth.big_document(1_000_000_000), None, {"_no_verify": "1"}),
              ("CJK text x VC (a vocabulary trained on CJK-dense text: merges across every frequent pair of neighbouring "
-              "characters saturate the seam map, nothing is cut; data/vc12257_*)", "VC", False, lambda: synth.cjk_text(20_000), None, None)]
+              "characters saturate the seam map's first level; data/vc12257_*)", "VC", False, lambda: synth.cjk_text(20_000), None, None),
+             ("CJK paragraphs of characters drawn at random x VC (pairs the vocabulary never learnt: the seam map's second level cuts "
+              "nearly everywhere)", "VC", False, lambda: synth.cjk_paragraphs(20_000), None, None),
+             ("the same with HUTK_NO_SEAM2=1 (first level only)", "VC", False, lambda: synth.cjk_paragraphs(20_000),
+              {"HUTK_NO_SEAM2": "1"}, None)]
     ctxs = {}
     for label, vocab, merges, gen, env_ctx, env_run in cases:
         key = (vocab, merges, tuple(sorted((env_ctx or {}).items())))
