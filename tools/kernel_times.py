@@ -6,12 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from hutoken_amd import _capi, data, synth
 
-vp, sp, kw = data.vocab_files("VC" if sys.argv[1] == "cjktext" else "VG")
+vp, sp, kw = data.vocab_files("VC" if sys.argv[1] in ("cjktext", "cjkvc") else "VG")
 ctx = _capi.Context(vp, sp, kw["prefix"], kw["is_byte_encoder"])
 if sys.argv[1] == "words":
     d, o = synth.random_words(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 100000, 8)
 elif sys.argv[1] == "cjktext":
     d, o = synth.cjk_text(int(sys.argv[2]) if len(sys.argv) > 2 else 20000)
+elif sys.argv[1] == "cjkvc":  # characters drawn at random under the CJK-dense vocabulary
+    d, o = synth.cjk_paragraphs(int(sys.argv[2]) if len(sys.argv) > 2 else 20000)
 elif sys.argv[1] == "cjk":
     d, o = synth.cjk_paragraphs(int(sys.argv[2]) if len(sys.argv) > 2 else 50000)
 else:
