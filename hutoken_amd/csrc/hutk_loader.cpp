@@ -485,6 +485,13 @@ void seam2_build(Tables& T, const std::vector<uint64_t>& entries, const std::vec
         }
         for (int q = 0; q < 4; q++)
             for (uint64_t m = ends[l].last[q]; m; m &= m - 1) T.seam2_part[64 * q + __builtin_ctzll(m)] |= f;
+        if (getenv("HUTK_DEBUG_SEAM2") && atoi(getenv("HUTK_DEBUG_SEAM2")) > 1) {
+            fprintf(stderr, "  part entry: L =");
+            if (l < raw.size()) for (unsigned char ch : raw[l]) fprintf(stderr, " %02x", ch);
+            fprintf(stderr, " | R =");
+            if (r < raw.size()) for (unsigned char ch : raw[r]) fprintf(stderr, " %02x", ch);
+            fprintf(stderr, "  (l %u r %u first_hi %x)\n", l, r, f);
+        }
     }
     if (getenv("HUTK_DEBUG_SEAM2")) {
         size_t known = 0, part_bits = 0;
