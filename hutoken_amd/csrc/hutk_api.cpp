@@ -231,6 +231,7 @@ int upload_tables(hutk_ctx* c) {
         D.seam2_part = c->d_seam2.p;
         D.seam2_bits = c->d_seam2.p + 256;
         D.seam2_shift = T.seam2_shift;
+        D.seam2_cats = T.seam2_cats;
         D.seam2_on = D.seam_on && T.seam2_on && !(getenv("HUTK_NO_SEAM2") && atoi(getenv("HUTK_NO_SEAM2"))) ? 1 : 0;
     }
     {   // multi bits [8], unit offsets [257], units: one allocation
@@ -642,8 +643,15 @@ int hutk_debug_seam2_cut(const hutk_ctx* ctx, uint32_t a3, uint32_t b3) {
         return 0;
     if (!seam2_char3(a3) || !seam2_char3(b3)) return 0;
     if ((T.seam2_part[(a3 >> 16) & 0xFFu] >> (b3 & 31u)) & 1u) return 0;
-    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
-    return ((T.seam2_bits[h >> 5] >> (h & 31)) & 1u) ? 0 : 1;
+    const uint32_t kinds[5][2] = {{3, 3}, {3, 2}, {3, 1}, {1, 3}, {1, 2}};
+    for (auto& kk : kinds) {
+        if (!(T.seam2_cats & seam2_cat_bit(kk[0], kk[1]))) continue;
+        const uint32_t a = kk[0] == 3 ? a3 : (a3 >> 16) & 0xFFu;
+        const uint32_t b = kk[1] == 3 ? b3 : kk[1] == 2 ? (b3 & 0xFFFFu) : (b3 & 0xFFu);
+        const uint32_t h = seam2_hash(a, b, kk[0], kk[1]) >> T.seam2_shift;
+        if ((T.seam2_bits[h >> 5] >> (h & 31)) & 1u) return 0;
+    }
+    return 1;
 }
 void hutk_set_timing(hutk_ctx* ctx, int enabled) {
     if (ctx) ctx->timing = enabled != 0;

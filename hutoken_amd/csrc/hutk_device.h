@@ -78,6 +78,7 @@ struct DevTables {
     const uint32_t* seam2_bits;
     const uint32_t* seam2_part;
     uint32_t seam2_shift;
+    uint32_t seam2_cats;
     int32_t seam2_on;
     // items with a replacement of several units, or of none (Tables::multi_bits): bit b of multi_bits[8]; the units of
     // item b are item_units[item_units_off[b] .. item_units_off[b + 1]).  has_multi == 0: every item is one unit.

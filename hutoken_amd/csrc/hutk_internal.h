@@ -184,13 +184,16 @@ struct Tables {
     bool seam_on = false;
     // Second level, consulted where seam_hi says "may join" and both sides of the boundary are whole three-byte characters A | B
     // (hutk_loader.cpp, seam2_build): a merge can join across A | B only if seam2_part[last byte of A] has B's lead byte's bit
-    // (entries whose left side does not end, or whose right side does not begin, with a whole three-byte character) or bit
-    // seam2_hash(A, B) >> seam2_shift of seam2_bits is set (entries that do: a hashed set of character pairs; a false
-    // positive costs a cut, nothing else).  For vocabularies whose merges cover every (last byte, lead byte) pair but
+    // (entries of which no more than those two bytes is known) or the hashed set seam2_bits holds one of the keys (A, B),
+    // (A, B's first two bytes), (A, B's lead byte), (A's last byte, B), (A's last byte, B's first two bytes) -- hutk_seam2.h:
+    // entries whose left side ends with a whole character, whose right side begins with one or IS the two-byte prefix of
+    // one (byte-level BPE on CJK text learns such tokens: a character + the prefix that sixty-four others share).  A false
+    // positive costs a cut, nothing else.  For vocabularies whose merges cover every (last byte, lead byte) pair but
     // join only the character pairs of their frequent words (trained on CJK text).
     std::vector<uint32_t> seam2_bits;
     uint32_t seam2_part[256] = {0};
     uint32_t seam2_shift = 0;
+    uint32_t seam2_cats = 0;  // kinds of keys the set holds, seam2_cat_bit(kind of the left part, kind of the right part)
     bool seam2_on = false;
 
     bool is_byte_encoder = false;

@@ -100,9 +100,14 @@ __device__ __forceinline__ uint32_t win24(uint64_t lo, uint64_t hi, int s) {
 }
 __device__ __forceinline__ bool seam2_cuts(const DevTables& T, uint32_t a3, uint32_t b3) {
     if (!seam2_char3(a3) || !seam2_char3(b3)) return false;
-    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
-    const uint32_t part = T.seam2_part[(a3 >> 16) & 0xFFu], bits = T.seam2_bits[h >> 5];  // (both loads in flight)
-    return !((part >> (b3 & 31u)) & 1u) && !((bits >> (h & 31u)) & 1u);
+    uint32_t hit = (T.seam2_part[(a3 >> 16) & 0xFFu] >> (b3 & 31u)) & 1u;
+    auto ask = [&](uint32_t ka, uint32_t kb) {
+        if (!(T.seam2_cats & seam2_cat_bit(ka, kb))) return;
+        const uint32_t h = seam2_hash(ka == 3 ? a3 : (a3 >> 16) & 0xFFu, kb == 3 ? b3 : kb == 2 ? (b3 & 0xFFFFu) : (b3 & 0xFFu), ka, kb) >> T.seam2_shift;
+        hit |= (T.seam2_bits[h >> 5] >> (h & 31u)) & 1u;
+    };
+    ask(3, 3); ask(3, 2); ask(3, 1); ask(1, 3); ask(1, 2);
+    return !hit;
 }
 
 // __syncthreads() of a workgroup that is ONE wavefront, without the s_barrier: the same fences, so that what one lane wrote

@@ -472,42 +472,64 @@ void seam2_build(Tables& T, const std::vector<uint64_t>& entries, const std::vec
         *out = c;
         return seam2_char3(c);
     };
-    std::vector<std::pair<uint32_t, uint32_t>> full;
+    struct Key { uint32_t a, b, ka, kb; };
+    std::vector<Key> keys;
+    size_t n_full = 0;
     for (uint64_t e : entries) {
         const uint32_t l = (uint32_t)e & 0xFFFFFu, r = ((uint32_t)e >> 20) | (((uint32_t)(e >> 32) & 0xFFu) << 12);
         if (l >= ends.size() || r >= ends.size()) continue;
         const uint32_t f = ends[r].first_hi;
         if (!f) continue;  // (R never begins with a byte >= 0xE0: no seam is asked about)
         uint32_t a3 = 0, b3 = 0;
-        if (l < raw.size() && r < raw.size() && tail3(raw[l], &a3) && head3(raw[r], &b3)) {
-            full.push_back({a3, b3});
+        const bool la = l < raw.size() && tail3(raw[l], &a3);   // L ends with the whole character a3
+        uint32_t kb = 1;                                        // what is known of R's beginning
+        if (r < raw.size() && head3(raw[r], &b3)) kb = 3;
+        else if (r < raw.size() && raw[r].size() == 2 && ((unsigned char)raw[r][0] & 0xF0u) == 0xE0u && ((unsigned char)raw[r][1] & 0xC0u) == 0x80u) {
+            kb = 2;
+            b3 = (uint32_t)(unsigned char)raw[r][0] | ((uint32_t)(unsigned char)raw[r][1] << 8);
+        }
+        if (!la && kb == 1) {  // two bytes: the first level's kind of entry
+            for (int q = 0; q < 4; q++)
+                for (uint64_t m = ends[l].last[q]; m; m &= m - 1) T.seam2_part[64 * q + __builtin_ctzll(m)] |= f;
+            if (getenv("HUTK_DEBUG_SEAM2") && atoi(getenv("HUTK_DEBUG_SEAM2")) > 1) {
+                fprintf(stderr, "  part entry: L =");
+                if (l < raw.size()) for (unsigned char ch : raw[l]) fprintf(stderr, " %02x", ch);
+                fprintf(stderr, " | R =");
+                if (r < raw.size()) for (unsigned char ch : raw[r]) fprintf(stderr, " %02x", ch);
+                fprintf(stderr, "  (l %u r %u first_hi %x)\n", l, r, f);
+            }
             continue;
         }
-        for (int q = 0; q < 4; q++)
-            for (uint64_t m = ends[l].last[q]; m; m &= m - 1) T.seam2_part[64 * q + __builtin_ctzll(m)] |= f;
-        if (getenv("HUTK_DEBUG_SEAM2") && atoi(getenv("HUTK_DEBUG_SEAM2")) > 1) {
-            fprintf(stderr, "  part entry: L =");
-            if (l < raw.size()) for (unsigned char ch : raw[l]) fprintf(stderr, " %02x", ch);
-            fprintf(stderr, " | R =");
-            if (r < raw.size()) for (unsigned char ch : raw[r]) fprintf(stderr, " %02x", ch);
-            fprintf(stderr, "  (l %u r %u first_hi %x)\n", l, r, f);
-        }
+        n_full += la && kb == 3;
+        // the left parts: the character, or every byte L can end with; the right parts: the character / prefix, or every lead byte
+        std::vector<uint32_t> as, bs;
+        if (la) as.push_back(a3);
+        else
+            for (int q = 0; q < 4; q++)
+                for (uint64_t m = ends[l].last[q]; m; m &= m - 1) as.push_back((uint32_t)(64 * q + __builtin_ctzll(m)));
+        if (kb != 1) bs.push_back(b3);
+        else
+            for (uint32_t m = f; m; m &= m - 1) bs.push_back(0xE0u + (uint32_t)__builtin_ctz(m));
+        for (uint32_t a : as)
+            for (uint32_t b : bs) keys.push_back({a, b, la ? 3u : 1u, kb});
     }
     if (getenv("HUTK_DEBUG_SEAM2")) {
         size_t known = 0, part_bits = 0;
         for (auto& r : raw) known += !r.empty();
         for (int x = 0; x < 256; x++) part_bits += __builtin_popcount(T.seam2_part[x]);
-        fprintf(stderr, "seam2: %zu entries, %zu of whole characters, %zu of %zu symbols with known bytes, %zu bits in the part map\n",
-                entries.size(), full.size(), known, raw.size(), part_bits);
+        fprintf(stderr, "seam2: %zu entries, %zu of whole characters, %zu keys, %zu of %zu symbols with known bytes, %zu bits in the part map\n",
+                entries.size(), n_full, keys.size(), known, raw.size(), part_bits);
     }
-    if (full.empty()) return;  // (nothing the first level does not say already)
+    if (keys.empty()) return;  // (nothing the first level does not say already)
     uint32_t lg = 16;
-    while (lg < 24 && ((size_t)1 << lg) < full.size() * 32) lg++;
+    while (lg < 24 && ((size_t)1 << lg) < keys.size() * 32) lg++;
     T.seam2_shift = 32 - lg;
     T.seam2_bits.assign(((size_t)1 << lg) / 32, 0u);
-    for (auto& ab : full) {
-        const uint32_t h = seam2_hash(ab.first, ab.second) >> T.seam2_shift;
+    T.seam2_cats = 0;
+    for (auto& k : keys) {
+        const uint32_t h = seam2_hash(k.a, k.b, k.ka, k.kb) >> T.seam2_shift;
         T.seam2_bits[h >> 5] |= 1u << (h & 31);
+        T.seam2_cats |= seam2_cat_bit(k.ka, k.kb);
     }
     T.seam2_on = true;
 }

@@ -475,12 +475,12 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                 // Second level (Tables::seam2_*): whole three-byte characters A | B on both sides of such a boundary -- a lane has
                 // at most six lead bytes among its sixteen positions; their two loads each are all in flight before any is used
                 if (T.seam2_on && __any(ask2 != 0)) {
-                    for (uint32_t nn = ask2; __any(nn != 0);) {  // three at a time (registers), at most two rounds
-                        uint32_t part[3], bits[3], meta[3];      // meta: bit of the set | lead byte's bit << 5 | my position << 10
+                    for (uint32_t nn = ask2; __any(nn != 0);) {  // three boundaries at a time (registers), at most two rounds
+                        uint32_t a3v[3], b3v[3], hit[3];  // hit: bit 0 = some entry may join here; bits 8.. = my position
 #pragma unroll
                         for (int k = 0; k < 3; k++) {
-                            part[k] = bits[k] = 0xFFFFFFFFu;  // ("may join")
-                            meta[k] = 0;
+                            a3v[k] = b3v[k] = 0;
+                            hit[k] = 1u;  // ("may join": nothing to ask)
                             if (nn) {
                                 const int j = __builtin_ctz(nn);
                                 nn &= nn - 1;
@@ -489,16 +489,31 @@ __global__ __launch_bounds__(64 * PT_WAVES) __attribute__((amdgpu_waves_per_eu(P
                                 const uint32_t a3 = win24(qa == 0 ? w.a : qa == 1 ? w.b : w.c, qa == 0 ? w.b : qa == 1 ? w.c : w.d, 8 * (oa & 7));
                                 const uint32_t b3 = win24(qb == 1 ? w.b : w.c, qb == 1 ? w.c : w.d, 8 * (ob & 7));
                                 if (seam2_char3(a3) && seam2_char3(b3)) {
-                                    const uint32_t h = seam2_hash(a3, b3) >> T.seam2_shift;
-                                    part[k] = T.seam2_part[(a3 >> 16) & 0xFFu];
-                                    bits[k] = T.seam2_bits[h >> 5];
-                                    meta[k] = (h & 31u) | ((b3 & 31u) << 5) | ((uint32_t)j << 10);
+                                    a3v[k] = a3;
+                                    b3v[k] = b3;
+                                    hit[k] = ((T.seam2_part[(a3 >> 16) & 0xFFu] >> (b3 & 31u)) & 1u) | ((uint32_t)j << 8);
                                 }
                             }
                         }
+                        // the kinds of keys this vocabulary's set holds (hutk_seam2.h), one after the other, a kind's three lookups together
+                        auto ask = [&](uint32_t ka, uint32_t kb) {
+                            if (!(T.seam2_cats & seam2_cat_bit(ka, kb))) return;  // (the same for every lane)
+                            uint32_t wd[3], hb[3];
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                const uint32_t a = ka == 3 ? a3v[k] : (a3v[k] >> 16) & 0xFFu;
+                                const uint32_t bb = kb == 3 ? b3v[k] : kb == 2 ? (b3v[k] & 0xFFFFu) : (b3v[k] & 0xFFu);
+                                const uint32_t h = seam2_hash(a, bb, ka, kb) >> T.seam2_shift;
+                                wd[k] = T.seam2_bits[h >> 5];
+                                hb[k] = h & 31u;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 3; k++) hit[k] |= (wd[k] >> hb[k]) & 1u;
+                        };
+                        ask(3, 3); ask(3, 2); ask(3, 1); ask(1, 3); ask(1, 2);
 #pragma unroll
                         for (int k = 0; k < 3; k++)
-                            if (!((part[k] >> ((meta[k] >> 5) & 31u)) & 1u) && !((bits[k] >> (meta[k] & 31u)) & 1u)) flags |= 1u << (meta[k] >> 10);
+                            if (!(hit[k] & 1u)) flags |= 1u << (hit[k] >> 8);
                     }
                 }
             }
