@@ -326,6 +326,34 @@ def test_g11_cjk_dense_vocabulary():
         assert sha_ids(res) == g["sha256"]
 
 
+def test_second_level_of_the_seam_map(oracle_mod):
+    """VC on batches large enough for k_ptiles, which asks the seam map's second level (whole characters, hutk_seam2.h) where
+    the byte map says "may join": the vocabulary's own distribution (a cut at one boundary in five) and characters drawn at
+    random (cut nearly everywhere).  Every id against the oracle -- with the level, without it (HUTK_NO_SEAM2=1), and
+    through k_tiles, which does not ask it (HUTK_PTILES=0)."""
+    import os
+    from hutoken_amd import data, synth
+    vp, sp, kw = data.vocab_files("VC")
+    orc = oracle_mod.Oracle(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+    for gen in (lambda: synth.cjk_text(1800), lambda: synth.cjk_paragraphs(1500)):
+        d, o = gen()
+        assert (len(d) + 959) // 960 >= 2048
+        ids_o, oo_o, _ = orc.encode_packed(d, o, 8)
+        for env in ({}, {"HUTK_NO_SEAM2": "1"}, {"HUTK_PTILES": "0"}):
+            old = {k: os.environ.pop(k, None) for k in ("HUTK_NO_SEAM2", "HUTK_PTILES")}
+            os.environ.update(env)
+            try:
+                ctx = ctx_for(vp, sp, kw["prefix"], kw["is_byte_encoder"])
+                ids, oo, st, rc = ctx.encode_packed(d, o)
+            finally:
+                for k in ("HUTK_NO_SEAM2", "HUTK_PTILES"):
+                    os.environ.pop(k, None)
+                    if old[k] is not None:
+                        os.environ[k] = old[k]
+            assert rc == 0
+            assert np.array_equal(oo, oo_o) and np.array_equal(ids, ids_o), env
+
+
 def test_batches_the_persistent_tile_kernel_is_chosen_for(oracle_mod):
     """A batch of a few thousand tiles dense in three-byte characters: the default mode enqueues both tile kernels and the
     sample k_pre takes of the batch makes k_ptiles the one that runs (hutk_api.cpp, Workspace::select); mixed text of the same
